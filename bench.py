@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- corner-residuals/sec of the device-side calibrateCamera LM loop (BASELINE.json).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): BASELINE.json configs[2] -- synthetic pinhole + k1,k2,p1,p2,
+1000 images x 9x6 corners per GPU (SURVEY.md 8d recipe, cameracalibrations_amd/synthetic.py),
+observed corners resident in HBM before the timed region.  With N GPUs every rank holds its
+own 1000-image shard of ONE joint fit (shared intrinsics): weak scaling, one RCCL all-reduce of
+the 112-double reduced system per LM trial.
+
+One step = one complete global LM solve from the closed-form initial
+values (rows A4/A5 run once on the device before timing and are reported separately, as
+SURVEY.md 8d defines the metric).  value = corner-residual evaluations (each with its
+2x(6+K) Jacobian block accumulated) per second over the whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+
+def algorithmic_bytes_per_sweep(N, P):
+    """SURVEY.md 8d contract figure: 8 B corner read + 96/P B pose read+write per corner-residual."""
+    return N * P * (8.0 + 96.0 / P)
+
+
+def cpu_baseline(wl, criteria, budget_s=12.0):
+    """The oracle (plain-C port of the reference algorithm, Schur mode, OpenMP over images)
+    timed on the host cores on the same workload; repeats until ~budget_s of CPU work."""
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    units, t_lm, reps = 0, 0.0, 0
+    t0 = time.time()
+    while time.time() - t0 < budget_s and reps < 200:
+        r = orc.calibrate(wl.obj, wl.img, wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=criteria[0],
+                          eps=criteria[1], solver="schur", nthreads=cores)
+        units += wl.n_images * wl.n_points * (r["j_sweeps"] + r["e_sweeps"])
+        t_lm += r["t_lm_s"]
+        reps += 1
+    return {"value": units / t_lm, "unit": "corner-residuals/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x full {wl.name} fit ({wl.n_images} x {wl.n_points}), criteria {criteria}, "
+                      f"oracle Schur mode, LM loop only; rms {r['rms']:.6f} px, iters {r['iters']}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="C3")
+    ap.add_argument("--images", type=int, default=None, help="override images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--allreduce", default=os.environ.get("CCAL_ALLREDUCE", "torch"), choices=["torch"])
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from cameracalibrations_amd import synthetic as syn
+    from cameracalibrations_amd.distributed import TorchAllReduce
+    from cameracalibrations_amd.solver import CRITERIA, Solver
+
+    world = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run --nproc-per-node N"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank)
+
+    # per-rank shard of the joint problem (different images on every rank, same camera)
+    wl = syn.named_workload(args.workload, n_images=args.images, seed_offset=1000 * rank)
+    N, P = wl.n_images, wl.n_points
+    img_dev = torch.from_numpy(wl.img).to(dev)                      # inputs resident in HBM
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    s = Solver(local_rank, stream=stream)
+    s.set_problem(wl.obj, N, wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=CRITERIA[0], eps=CRITERIA[1])
+    s.set_image_points(img_dev)
+    if world > 1:
+        s.set_allreduce(TorchAllReduce(), world, rank, N * world)
+    s.init_intrinsics()
+    s.init_extrinsics()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        s.lm_run()
+    # --- timed region: exactly K steps -------------------------------------------------
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        s.lm_run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    r = s.result()
+    sweeps = r["sweeps"] * args.steps                # deterministic: every step repeats the same solve
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # --- sweep-kernel duration, HIP events on the launch stream, same steps re-run -------
+    s.set_sweep_timing(True)
+    us, n_timed, t1 = 0.0, 0, time.perf_counter()
+    for _ in range(args.steps):
+        s.lm_run()
+        rr = s.result()
+        us += rr["sweep_us"] * rr["timed_sweeps"]
+        n_timed += rr["timed_sweeps"]
+    torch.cuda.synchronize()
+    elapsed_events = time.perf_counter() - t1
+    s.set_sweep_timing(False)
+    sweep_us = us / max(n_timed, 1)
+    sweep_us_b2b = s.time_sweep(200)
+
+    # --- separately reported: closed-form init and a full fit ---------------------------
+    t2 = time.perf_counter()
+    s.init_intrinsics()
+    s.init_extrinsics()
+    s.lm_run()
+    torch.cuda.synchronize()
+    fit_ms = 1e3 * (time.perf_counter() - t2)
+    rf = s.result()
+
+    # --- converged criteria (100, 1e-10): iters-to-tol -----------------------------------
+    s.set_problem(wl.obj, N, wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=100, eps=1e-10)
+    s.set_image_points(img_dev)
+    if world > 1:
+        s.set_allreduce(TorchAllReduce(), world, rank, N * world)
+    s.init_intrinsics()
+    s.init_extrinsics()
+    s.lm_run()
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    for _ in range(10):
+        s.lm_run()
+    torch.cuda.synchronize()
+    tight_ms = 1e2 * (time.perf_counter() - t3)
+    rt = s.result()
+
+    if rank == 0:
+        units = float(N) * world * P * sweeps
+        alg_bytes = algorithmic_bytes_per_sweep(N, P)
+        achieved = alg_bytes / (sweep_us * 1e-6) / 1e9 if sweep_us > 0 else 0.0
+        out = {
+            "metric": "corner-residuals/sec + LM iters-to-tol, 1000 imgs x 9x6 corners, 1/2/4/8 GPU",
+            "value": units / elapsed,
+            "unit": "corner-residuals/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{wl.name}: synthetic pinhole + k1,k2,p1,p2, {N} images x "
+                                   f"{wl.n_corners[0]}x{wl.n_corners[1]} corners per GPU (BASELINE.json configs[2]), "
+                                   f"one joint fit over {world} GPU(s)",
+                       "images_per_gpu": N, "corners_per_image": P, "free_intrinsics": 8, "flags": wl.flags,
+                       "criteria": list(CRITERIA), "step": "global LM solve (A6-A9) from device-side init",
+                       "parallelism": f"image-sharded x{world}" if world > 1 else "single GPU"},
+            "lm": {"iters_to_tol_1e-3": r["iters"], "sweeps_per_solve": r["sweeps"], "rejected": r["rejected"],
+                   "rms_px": r["rms"], "iters_to_tol_1e-10": rt["iters"], "sweeps_1e-10": rt["sweeps"],
+                   "rms_px_1e-10": rt["rms"], "ms_per_solve_1e-10": tight_ms},
+            "init": {"intrinsics_ms": 1e3 * rf["t_init_intr_s"], "extrinsics_ms": 1e3 * rf["t_init_extr_s"],
+                     "full_fit_ms": fit_ms},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ccal::k_lm_sweep", "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_us": sweep_us, "launches_timed": n_timed,
+                         "avg_launch_us_back_to_back": sweep_us_b2b,
+                         "timed_region_with_events_ms_per_step": 1e3 * elapsed_events / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, CRITERIA)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

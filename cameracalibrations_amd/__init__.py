@@ -1,0 +1,10 @@
+"""MI355X-native camera-model fit: drop-in for the `fit_model` / point-map path of
+yakir12/CameraCalibrations.  HIP kernels live in csrc/, the C ABI in
+include/ccal.h; this package is the Python mirror of the reference's Julia interface.
+Importing it needs no GPU; every compute call does (there is no CPU fallback)."""
+from .calibration import (Calibration, RowCol, XYZ, board_template, calculate_errors, fit, fit_corners,  # noqa: F401
+                          obj2img, rectification)
+from .solver import CRITERIA, Solver, device_count, fit_model, reference_flags  # noqa: F401
+
+__all__ = ["fit", "fit_corners", "fit_model", "Calibration", "RowCol", "XYZ", "rectification", "calculate_errors",
+           "obj2img", "board_template", "Solver", "device_count", "reference_flags", "CRITERIA"]

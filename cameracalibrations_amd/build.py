@@ -1,0 +1,50 @@
+"""Builds libccal_hip.so (gfx950 kernels + C ABI) in-tree with hipcc.
+
+    python -m cameracalibrations_amd.build        # or __graft_entry__.build()
+
+hipcc cross-compiles for gfx950 without a GPU.  The library links libamdhip64.so.7 by
+soname: inside a Python process that imported torch first, the loader binds it to torch's
+already-loaded HIP runtime, so torch streams / device pointers are directly usable.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SOURCES = ["ccal_lm.hip", "ccal_init.hip", "ccal_maps.hip", "ccal_api.hip"]
+HEADERS = ["ccal_math.hpp", "ccal_state.hpp", "ccal_wave.hpp", "ccal_kernels.hpp", "../../include/ccal.h"]
+LIB = os.path.join(HERE, "libccal_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

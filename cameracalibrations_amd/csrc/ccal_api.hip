@@ -1,0 +1,679 @@
+// ccal_api.hip -- C ABI (include/ccal.h) and host driver of the device-side fit.
+//
+// Host work is limited to marshalling, launching and polling the device-side `done` flag;
+// every arithmetic stage of calibrateCamera (reference src/detect_fit.jl:47) runs in the
+// gfx950 kernels.  There is no CPU fallback: without a HIP device every entry fails.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ccal.h"
+#include "ccal_kernels.hpp"
+#include "ccal_state.hpp"
+
+using namespace ccal;
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(CCAL_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));   \
+    } while (0)
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct ccal_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // problem
+    int P = 0, N = 0, width = 0, height = 0, max_iter = 30;
+    double aspect = 1.0, eps = 1e-3;
+    uint32_t flags = 0;
+    bool planar_z0 = false;
+    // device buffers
+    float *d_obj = nullptr, *d_img_own = nullptr;
+    const float *d_img = nullptr;
+    size_t img_cap = 0, n_cap = 0;
+    int p_cap = 0;
+    double *d_ext = nullptr, *d_ext0 = nullptr, *d_blk = nullptr, *d_partials = nullptr, *d_red = nullptr;
+    double *d_H = nullptr, *d_foc_partials = nullptr, *d_foc_red = nullptr, *d_gram = nullptr;
+    int *d_fail = nullptr;
+    LmState *d_st = nullptr, *d_st_scratch = nullptr;
+    TraceRec *d_trace = nullptr;
+    int max_trace = 4096;
+    // pinned host mirrors
+    LmState *h_st = nullptr;
+    int *h_flags = nullptr;
+    // stage bookkeeping
+    bool have_problem = false, have_img = false, have_intr = false, have_ext = false, have_result = false;
+    double intr0[CCAL_NINTR] = {0};
+    ccal_stats stats{};
+    // multi-GPU
+    ccal_allreduce_fn ar_fn = nullptr;
+    void *ar_user = nullptr;
+    int world = 1, rank = 0;
+    int64_t n_global = 0;
+    int lm_batch = 4;
+    // optional per-sweep event timing
+    bool time_sweeps = false;
+    std::vector<hipEvent_t> ev;   // 2 * MAX_KINDS events, created on demand
+    int ev_used = 0;
+};
+
+static void free_problem_buffers(ccal_ctx *c) {
+    (void)hipFree(c->d_obj); (void)hipFree(c->d_img_own); (void)hipFree(c->d_ext); (void)hipFree(c->d_ext0); (void)hipFree(c->d_blk); (void)hipFree(c->d_partials);
+    (void)hipFree(c->d_H); (void)hipFree(c->d_foc_partials); (void)hipFree(c->d_gram);
+    c->d_obj = nullptr; c->d_img_own = nullptr; c->d_ext = c->d_ext0 = c->d_blk = c->d_partials = nullptr;
+    c->d_H = c->d_foc_partials = c->d_gram = nullptr;
+    c->img_cap = 0; c->n_cap = 0; c->p_cap = 0;
+}
+
+extern "C" {
+
+int ccal_version(void) { return CCAL_VERSION; }
+const char *ccal_last_error(void) { return g_err.c_str(); }
+
+int ccal_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+int ccal_create(int device, ccal_ctx **out) {
+    if (!out) return fail(CCAL_E_ARG, "ccal_create: out == NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(CCAL_E_DEVICE, "ccal_create: no HIP device visible (this library has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(CCAL_E_ARG, "ccal_create: bad device index");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(CCAL_E_DEVICE, std::string("ccal_create: kernels are built for gfx950 only, device is ") +
+                                       prop.gcnArchName);
+    HIPCHK(hipSetDevice(device));
+    ccal_ctx *c = new ccal_ctx();
+    c->device = device;
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIPCHK(hipMalloc(&c->d_st, sizeof(LmState)));
+    HIPCHK(hipMalloc(&c->d_st_scratch, sizeof(LmState)));
+    HIPCHK(hipMalloc(&c->d_red, sizeof(double) * NRED));
+    HIPCHK(hipMalloc(&c->d_foc_red, sizeof(double) * NFOC));
+    HIPCHK(hipMalloc(&c->d_fail, sizeof(int) * 4));
+    HIPCHK(hipMalloc(&c->d_trace, sizeof(TraceRec) * c->max_trace));
+    HIPCHK(hipHostMalloc(&c->h_st, sizeof(LmState), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&c->h_flags, sizeof(int) * 16, hipHostMallocDefault));
+    const char *b = getenv("CCAL_LM_BATCH");
+    if (b && atoi(b) > 0) c->lm_batch = atoi(b);
+    *out = c;
+    return CCAL_OK;
+}
+
+void ccal_destroy(ccal_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_problem_buffers(c);
+    (void)hipFree(c->d_st); (void)hipFree(c->d_st_scratch); (void)hipFree(c->d_red); (void)hipFree(c->d_foc_red); (void)hipFree(c->d_fail);
+    (void)hipFree(c->d_trace);
+    (void)hipHostFree(c->h_st); (void)hipHostFree(c->h_flags);
+    for (auto &e : c->ev) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int ccal_set_stream(ccal_ctx *c, void *hip_stream) {
+    if (!c) return fail(CCAL_E_ARG, "ccal_set_stream: ctx == NULL");
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return CCAL_OK;
+}
+
+int ccal_set_allreduce(ccal_ctx *c, ccal_allreduce_fn fn, void *user, int32_t world_size, int32_t rank,
+                       int64_t n_images_global) {
+    if (!c) return fail(CCAL_E_ARG, "ccal_set_allreduce: ctx == NULL");
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fail(CCAL_E_ARG, "ccal_set_allreduce: bad rank/world");
+    if (world_size > 1 && (!fn || n_images_global < 1)) return fail(CCAL_E_ARG, "ccal_set_allreduce: hook missing");
+    c->ar_fn = world_size > 1 ? fn : nullptr;
+    c->ar_user = user;
+    c->world = world_size;
+    c->rank = rank;
+    c->n_global = world_size > 1 ? n_images_global : 0;
+    return CCAL_OK;
+}
+
+int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_t width, int32_t height,
+                     double aspect, uint32_t flags, int32_t max_iter, double eps) {
+    if (!c || !obj) return fail(CCAL_E_ARG, "ccal_set_problem: NULL argument");
+    if (P < 4 || N < 1 || max_iter < 1 || !(eps >= 0)) return fail(CCAL_E_ARG, "ccal_set_problem: bad sizes/criteria");
+    const uint32_t known = CCAL_USE_INTRINSIC_GUESS | CCAL_FIX_ASPECT_RATIO | CCAL_FIX_PRINCIPAL_POINT |
+                           CCAL_ZERO_TANGENT_DIST | CCAL_FIX_FOCAL_LENGTH | CCAL_FIX_K1 | CCAL_FIX_K2 | CCAL_FIX_K3 |
+                           CCAL_FIX_TANGENT_DIST;
+    if (flags & ~known)
+        return fail(CCAL_E_ARG, "ccal_set_problem: unsupported flag (rational / thin-prism / tilted models are "
+                                "outside the reference's use, src/detect_fit.jl:40)");
+    if ((flags & CCAL_FIX_ASPECT_RATIO) && !(flags & CCAL_USE_INTRINSIC_GUESS) && !(aspect >= 0.01 && aspect <= 100))
+        return fail(CCAL_E_ARG, "ccal_set_problem: aspect ratio outside [0.01, 100]");
+    HIPCHK(hipSetDevice(c->device));
+    bool planar = true;
+    for (int p = 0; p < P; p++)
+        if (std::fabs(obj[3 * p + 2]) > 1e-5f) planar = false;
+    c->planar_z0 = planar;
+    if ((size_t)N > c->n_cap || P > c->p_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        free_problem_buffers(c);
+        const size_t n = (size_t)N;
+        HIPCHK(hipMalloc(&c->d_obj, sizeof(float) * 3 * P));
+        HIPCHK(hipMalloc(&c->d_ext, sizeof(double) * 2 * n * EXT));
+        HIPCHK(hipMalloc(&c->d_ext0, sizeof(double) * n * EXT));
+        HIPCHK(hipMalloc(&c->d_blk, sizeof(double) * 2 * n * BLK));
+        HIPCHK(hipMalloc(&c->d_partials, sizeof(double) * (size_t)lm_sweep_blocks(N) * NRED));
+        HIPCHK(hipMalloc(&c->d_H, sizeof(double) * n * 9));
+        HIPCHK(hipMalloc(&c->d_foc_partials, sizeof(double) * n * NFOC));
+        c->n_cap = n;
+        c->p_cap = P;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_obj, obj, sizeof(float) * 3 * P, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_ext, 0, sizeof(double) * 2 * (size_t)N * EXT, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_ext0, 0, sizeof(double) * (size_t)N * EXT, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));   // `obj` may be released by the caller after return
+    c->P = P; c->N = N; c->width = width; c->height = height; c->aspect = aspect; c->flags = flags;
+    c->max_iter = max_iter; c->eps = eps;
+    c->have_problem = true;
+    c->have_img = c->have_intr = c->have_ext = c->have_result = false;
+    c->d_img = nullptr;
+    memset(&c->stats, 0, sizeof c->stats);
+    return CCAL_OK;
+}
+
+int ccal_set_image_points(ccal_ctx *c, const float *img_host) {
+    if (!c || !img_host) return fail(CCAL_E_ARG, "ccal_set_image_points: NULL argument");
+    if (!c->have_problem) return fail(CCAL_E_STATE, "ccal_set_image_points: call ccal_set_problem first");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t need = sizeof(float) * 2 * (size_t)c->P * c->N;
+    if (need > c->img_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipFree(c->d_img_own);
+        c->d_img_own = nullptr;
+        HIPCHK(hipMalloc(&c->d_img_own, need));
+        c->img_cap = need;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_img_own, img_host, need, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->d_img = c->d_img_own;
+    c->have_img = true;
+    c->have_result = false;
+    return CCAL_OK;
+}
+
+int ccal_set_image_points_device(ccal_ctx *c, const float *img_device) {
+    if (!c || !img_device) return fail(CCAL_E_ARG, "ccal_set_image_points_device: NULL argument");
+    if (!c->have_problem) return fail(CCAL_E_STATE, "ccal_set_image_points_device: call ccal_set_problem first");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, img_device) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+        (void)hipGetLastError();
+        return fail(CCAL_E_ARG, "ccal_set_image_points_device: not a device pointer");
+    }
+    c->d_img = img_device;
+    c->have_img = true;
+    c->have_result = false;
+    return CCAL_OK;
+}
+
+int ccal_set_intrinsics(ccal_ctx *c, const double intr[CCAL_NINTR]) {
+    if (!c || !intr) return fail(CCAL_E_ARG, "ccal_set_intrinsics: NULL argument");
+    if (!c->have_problem) return fail(CCAL_E_STATE, "ccal_set_intrinsics: call ccal_set_problem first");
+    for (int a = 0; a < CCAL_NINTR; a++)
+        if (!std::isfinite(intr[a])) return fail(CCAL_E_ARG, "ccal_set_intrinsics: non-finite value");
+    if (!(intr[0] > 0 && intr[1] > 0)) return fail(CCAL_E_ARG, "ccal_set_intrinsics: focal lengths must be > 0");
+    memcpy(c->intr0, intr, sizeof c->intr0);
+    c->have_intr = true;
+    c->have_result = false;
+    return CCAL_OK;
+}
+
+int ccal_set_extrinsics(ccal_ctx *c, const double *rt_host) {
+    if (!c || !rt_host) return fail(CCAL_E_ARG, "ccal_set_extrinsics: NULL argument");
+    if (!c->have_problem) return fail(CCAL_E_STATE, "ccal_set_extrinsics: call ccal_set_problem first");
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<double> padded((size_t)c->N * EXT, 0.0);
+    for (int i = 0; i < c->N; i++)
+        for (int k = 0; k < 6; k++) padded[(size_t)i * EXT + k] = rt_host[(size_t)i * 6 + k];
+    HIPCHK(hipMemcpyAsync(c->d_ext0, padded.data(), sizeof(double) * padded.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_ext = true;
+    c->have_result = false;
+    return CCAL_OK;
+}
+
+// ---- A4 / A5: closed-form initialisation on the device ---------------------------------
+static int run_allreduce(ccal_ctx *c, double *buf, int n) {
+    if (c->world <= 1 || !c->ar_fn) return CCAL_OK;
+    const int rc = c->ar_fn(c->ar_user, buf, n, (void *)c->stream);
+    if (rc != 0) return fail(CCAL_E_COMM, "all-reduce hook returned " + std::to_string(rc));
+    return CCAL_OK;
+}
+
+static void host_state_defaults(ccal_ctx *c, LmState &s) {
+    memset(&s, 0, sizeof s);
+    s.mode = MODE_INIT;
+    s.lambda_lg10 = -3;
+    s.lg_partials = -3;
+    s.lam_next = std::exp(-3.0 * std::log(10.0));
+    s.lam_step = s.lam_next;
+    s.max_iter = c->max_iter;
+    s.eps = c->eps;
+    s.max_trace = c->max_trace;
+    s.P = c->P;
+    s.N_local = c->N;
+    s.nblocks = lm_sweep_blocks(c->N);
+    s.N_global = c->world > 1 ? c->n_global : c->N;
+    // parameter mask from the flag word
+    const uint32_t f = c->flags;
+    for (int a = 0; a < 9; a++) s.mask[a] = 1;
+    if (f & CCAL_FIX_ASPECT_RATIO) s.mask[0] = 0;
+    if (f & CCAL_FIX_FOCAL_LENGTH) s.mask[0] = s.mask[1] = 0;
+    if (f & CCAL_FIX_PRINCIPAL_POINT) s.mask[2] = s.mask[3] = 0;
+    if (f & (CCAL_ZERO_TANGENT_DIST | CCAL_FIX_TANGENT_DIST)) s.mask[6] = s.mask[7] = 0;
+    if (f & CCAL_FIX_K1) s.mask[4] = 0;
+    if (f & CCAL_FIX_K2) s.mask[5] = 0;
+    if (f & CCAL_FIX_K3) s.mask[8] = 0;
+    s.aspect = 0.0;
+    if (f & CCAL_FIX_ASPECT_RATIO)
+        s.aspect = (f & CCAL_USE_INTRINSIC_GUESS) ? c->intr0[0] / c->intr0[1] : c->aspect;
+}
+
+int ccal_init_intrinsics(ccal_ctx *c) {
+    if (!c) return fail(CCAL_E_ARG, "ccal_init_intrinsics: ctx == NULL");
+    if (!c->have_problem || !c->have_img) return fail(CCAL_E_STATE, "ccal_init_intrinsics: problem/image points not set");
+    if (!c->planar_z0)
+        return fail(CCAL_E_NONPLANAR, "For non-planar calibration rigs the initial intrinsic matrix must be specified");
+    HIPCHK(hipSetDevice(c->device));
+    const double t0 = now_s();
+    LmState &s = *c->h_st;
+    host_state_defaults(c, s);
+    HIPCHK(hipMemcpyAsync(c->d_st, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_init_homography(c->stream, c->d_obj, c->d_img, c->d_H, c->d_foc_partials, c->N, c->P, c->width,
+                                  c->height));
+    HIPCHK(launch_init_focal_reduce(c->stream, c->d_foc_partials, c->d_foc_red, c->N));
+    int rc = run_allreduce(c, c->d_foc_red, NFOC);
+    if (rc) return rc;
+    const double aspect = (c->flags & CCAL_FIX_ASPECT_RATIO) ? c->aspect : 0.0;
+    HIPCHK(launch_init_focal_solve(c->stream, c->d_foc_red, c->d_st, c->width, c->height, aspect));
+    HIPCHK(hipMemcpyAsync(c->h_st, c->d_st, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->h_st->status != 0) return fail(CCAL_E_DEGENERATE, "ccal_init_intrinsics: homography estimation failed");
+    for (int a = 0; a < 9; a++) c->intr0[a] = c->h_st->intr_prev[a];
+    for (int a = 0; a < 4; a++)
+        if (!std::isfinite(c->intr0[a])) return fail(CCAL_E_DEGENERATE, "ccal_init_intrinsics: non-finite focal length");
+    c->have_intr = true;
+    c->have_result = false;
+    c->stats.t_init_intr_s = now_s() - t0;
+    return CCAL_OK;
+}
+
+int ccal_init_extrinsics(ccal_ctx *c) {
+    if (!c) return fail(CCAL_E_ARG, "ccal_init_extrinsics: ctx == NULL");
+    if (!c->have_problem || !c->have_img || !c->have_intr)
+        return fail(CCAL_E_STATE, "ccal_init_extrinsics: intrinsics / image points not set");
+    if (!c->planar_z0) return fail(CCAL_E_NONPLANAR, "ccal_init_extrinsics: only planar z = 0 templates are supported");
+    HIPCHK(hipSetDevice(c->device));
+    const double t0 = now_s();
+    LmState &s = *c->h_st;
+    host_state_defaults(c, s);
+    for (int a = 0; a < 9; a++) s.intr_prev[a] = c->intr0[a];
+    HIPCHK(hipMemcpyAsync(c->d_st, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_fail, 0, sizeof(int) * 4, c->stream));
+    HIPCHK(launch_init_extrinsics(c->stream, c->d_obj, c->d_img, c->d_st, c->d_ext0, c->d_fail, c->N, c->P));
+    HIPCHK(hipMemcpyAsync(c->h_flags, c->d_fail, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    c->stats.t_init_extr_s = now_s() - t0;
+    if (c->h_flags[0] != 0)
+        return fail(CCAL_E_DEGENERATE, "ccal_init_extrinsics: pose initialisation failed for " +
+                                           std::to_string(c->h_flags[0]) + " image(s)");
+    c->have_ext = true;
+    c->have_result = false;
+    return CCAL_OK;
+}
+
+// ---- A6-A9: global LM ------------------------------------------------------------------
+static int enqueue_trial(ccal_ctx *c) {
+    const bool timed = c->time_sweeps && c->ev_used < MAX_KINDS;
+    if (timed) HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], c->stream));
+    HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_ext, c->d_blk, c->d_st, c->d_partials, nullptr, c->N,
+                           c->P));
+    if (timed) HIPCHK(hipEventRecord(c->ev[2 * c->ev_used++ + 1], c->stream));
+    const int nb = lm_sweep_blocks(c->N);
+    if (c->world > 1 && c->ar_fn) {
+        HIPCHK(launch_lm_solve(c->stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nb, 1, 0));
+        const int rc = run_allreduce(c, c->d_red, NRED);
+        if (rc) return rc;
+        HIPCHK(launch_lm_solve(c->stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nb, 0, 1));
+    } else {
+        HIPCHK(launch_lm_solve(c->stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nb, 1, 1));
+    }
+    return CCAL_OK;
+}
+
+int ccal_lm_run(ccal_ctx *c) {
+    if (!c) return fail(CCAL_E_ARG, "ccal_lm_run: ctx == NULL");
+    if (!c->have_problem || !c->have_img || !c->have_intr || !c->have_ext)
+        return fail(CCAL_E_STATE, "ccal_lm_run: initial intrinsics / extrinsics / image points not set");
+    HIPCHK(hipSetDevice(c->device));
+    const double t0 = now_s();
+    LmState &s = *c->h_st;
+    host_state_defaults(c, s);
+    for (int a = 0; a < 9; a++) s.intr_prev[a] = c->intr0[a];
+    if (c->flags & CCAL_ZERO_TANGENT_DIST) s.intr_prev[6] = s.intr_prev[7] = 0.0;
+    if (s.aspect > 0.0) s.intr_prev[0] = s.aspect * s.intr_prev[1];
+    for (int a = 0; a < 9; a++) s.intr_cand[a] = s.intr_prev[a];
+    HIPCHK(hipMemcpyAsync(c->d_st, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+    // the loop starts from the stored initial poses (a fit can be re-run from the same start)
+    HIPCHK(hipMemcpyAsync(c->d_ext, c->d_ext0, sizeof(double) * (size_t)c->N * EXT, hipMemcpyDeviceToDevice, c->stream));
+    // upper bound on trials: every accepted iteration may be preceded by lambda climbing
+    // from -16 to 16 (rejections + re-Schur passes)
+    const long max_trials = 8L + (long)c->max_iter * 70L;
+    long trials = 0;
+    c->ev_used = 0;
+    c->h_flags[0] = 0;
+    while (trials < max_trials) {
+        for (int b = 0; b < c->lm_batch; b++) {
+            const int rc = enqueue_trial(c);
+            if (rc) return rc;
+        }
+        trials += c->lm_batch;
+        HIPCHK(hipMemcpyAsync(c->h_flags, &c->d_st->done, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->h_flags[0]) break;
+    }
+    HIPCHK(hipMemcpyAsync(c->h_st, c->d_st, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const LmState &r = *c->h_st;
+    c->stats.t_lm_s = now_s() - t0;
+    c->stats.iters = r.iters; c->stats.sweeps = r.sweeps; c->stats.reschur = r.reschur;
+    c->stats.rejected = r.rejected; c->stats.lambda_lg10 = r.lambda_lg10; c->stats.n_bad = r.n_bad;
+    c->stats.final_err = r.prev_err; c->stats.rel_step = r.rel_step;
+    c->stats.rms = std::sqrt(r.prev_err / ((double)r.N_global * (double)c->P));
+    c->stats.sweep_us = 0.0;
+    c->stats.timed_sweeps = 0;
+    if (c->time_sweeps) {
+        double sum_ms = 0.0;
+        int n = 0;
+        for (int t = 0; t < c->ev_used; t++) {
+            if (r.kinds[t] != 1 + MODE_INIT && r.kinds[t] != 1 + MODE_EVAL) continue;   // re-Schur / no-op launches
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * t], c->ev[2 * t + 1]));
+            sum_ms += ms;
+            n++;
+        }
+        c->stats.timed_sweeps = n;
+        c->stats.sweep_us = n ? 1000.0 * sum_ms / n : 0.0;
+    }
+    if (!r.done) return fail(CCAL_E_STATE, "ccal_lm_run: trial budget exhausted without termination");
+    c->have_result = true;
+    if (r.status == -4) return fail(CCAL_E_NONFINITE, "ccal_lm_run: non-finite reprojection error on the device");
+    if (r.status == -3) return fail(CCAL_E_DEGENERATE, "ccal_lm_run: reduced intrinsic system not positive definite");
+    return r.status == 1 ? CCAL_W_MAX_ITER : CCAL_OK;
+}
+
+int ccal_set_sweep_timing(ccal_ctx *c, int32_t enable) {
+    if (!c) return fail(CCAL_E_ARG, "ccal_set_sweep_timing: ctx == NULL");
+    HIPCHK(hipSetDevice(c->device));
+    if (enable && c->ev.empty()) {
+        c->ev.resize(2 * MAX_KINDS);
+        for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
+    }
+    c->time_sweeps = enable != 0;
+    return CCAL_OK;
+}
+
+int ccal_get_result(ccal_ctx *c, double intr[CCAL_NINTR], double *rvecs, double *tvecs, ccal_stats *stats) {
+    if (!c) return fail(CCAL_E_ARG, "ccal_get_result: ctx == NULL");
+    if (!c->have_result) return fail(CCAL_E_STATE, "ccal_get_result: no finished fit");
+    HIPCHK(hipSetDevice(c->device));
+    const LmState &r = *c->h_st;
+    if (intr) memcpy(intr, r.intr_prev, sizeof(double) * 9);
+    if (rvecs || tvecs) {
+        std::vector<double> e((size_t)c->N * EXT);
+        HIPCHK(hipMemcpyAsync(e.data(), c->d_ext + (size_t)r.parity * c->N * EXT, sizeof(double) * e.size(),
+                              hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < c->N; i++)
+            for (int k = 0; k < 3; k++) {
+                if (rvecs) rvecs[(size_t)3 * i + k] = e[(size_t)i * EXT + k];
+                if (tvecs) tvecs[(size_t)3 * i + k] = e[(size_t)i * EXT + 3 + k];
+            }
+    }
+    if (stats) *stats = c->stats;
+    return CCAL_OK;
+}
+
+int ccal_get_trace(ccal_ctx *c, ccal_trace *out, int32_t max_entries, int32_t *n_entries) {
+    if (!c || !n_entries) return fail(CCAL_E_ARG, "ccal_get_trace: NULL argument");
+    if (!c->have_result) return fail(CCAL_E_STATE, "ccal_get_trace: no finished fit");
+    HIPCHK(hipSetDevice(c->device));
+    int n = c->h_st->n_trace < c->max_trace ? c->h_st->n_trace : c->max_trace;
+    if (n > max_entries) n = max_entries;
+    *n_entries = n;
+    if (out && n > 0) {
+        static_assert(sizeof(ccal_trace) == sizeof(TraceRec), "trace record layouts differ");
+        HIPCHK(hipMemcpyAsync(out, c->d_trace, sizeof(TraceRec) * n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return CCAL_OK;
+}
+
+int ccal_get_init(ccal_ctx *c, double intr[CCAL_NINTR], double *rt_host) {
+    if (!c) return fail(CCAL_E_ARG, "ccal_get_init: ctx == NULL");
+    HIPCHK(hipSetDevice(c->device));
+    if (intr) {
+        if (!c->have_intr) return fail(CCAL_E_STATE, "ccal_get_init: no initial intrinsics");
+        memcpy(intr, c->intr0, sizeof c->intr0);
+    }
+    if (rt_host) {
+        if (!c->have_ext) return fail(CCAL_E_STATE, "ccal_get_init: no initial extrinsics");
+        std::vector<double> e((size_t)c->N * EXT);
+        HIPCHK(hipMemcpyAsync(e.data(), c->d_ext0, sizeof(double) * e.size(), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < c->N; i++)
+            for (int k = 0; k < 6; k++) rt_host[(size_t)6 * i + k] = e[(size_t)i * EXT + k];
+    }
+    return CCAL_OK;
+}
+
+// ---- one-shot drop-in ------------------------------------------------------------------
+int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int32_t width, int32_t height,
+                   double aspect, uint32_t flags, int32_t max_iter, double eps, int32_t device, double K4[4],
+                   double dist5[5], double *rvecs, double *tvecs, double *rms, int32_t *iters, ccal_stats *stats) {
+    if (!obj || !img) return fail(CCAL_E_ARG, "ccal_calibrate: NULL points");
+    ccal_ctx *c = nullptr;
+    int rc = ccal_create(device, &c);
+    if (rc < 0) return rc;
+    double intr[9];
+    int lm_rc = 0;
+    do {
+        if ((rc = ccal_set_problem(c, obj, P, N, width, height, aspect, flags, max_iter, eps)) < 0) break;
+        if ((rc = ccal_set_image_points(c, img)) < 0) break;
+        if (flags & CCAL_USE_INTRINSIC_GUESS) {
+            if (!K4 || !dist5) { rc = fail(CCAL_E_ARG, "ccal_calibrate: intrinsic guess requested but K4/dist5 NULL"); break; }
+            const double g[9] = {K4[0], K4[1], K4[2], K4[3], dist5[0], dist5[1], dist5[2], dist5[3], dist5[4]};
+            if ((rc = ccal_set_intrinsics(c, g)) < 0) break;
+        } else if ((rc = ccal_init_intrinsics(c)) < 0) break;
+        if ((rc = ccal_init_extrinsics(c)) < 0) break;
+        if ((lm_rc = rc = ccal_lm_run(c)) < 0) break;
+        ccal_stats st;
+        if ((rc = ccal_get_result(c, intr, rvecs, tvecs, &st)) < 0) break;
+        if (K4) memcpy(K4, intr, sizeof(double) * 4);
+        if (dist5) memcpy(dist5, intr + 4, sizeof(double) * 5);
+        if (rms) *rms = st.rms;
+        if (iters) *iters = st.iters;
+        if (stats) *stats = st;
+        rc = lm_rc;
+    } while (0);
+    const std::string keep = g_err;
+    ccal_destroy(c);
+    g_err = keep;
+    return rc;
+}
+
+// ---- point maps and error metrics (A11-A13) ---------------------------------------------
+namespace {
+struct DevBuf {                       // scratch device allocation, freed on scope exit
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+static int map_common(ccal_ctx *c, const double *in, int32_t M, int in_w, int out_w, const double f[2],
+                      const double cc[2], double k, const double rvec[3], const double tvec[3], double cs,
+                      double *out, bool forward) {
+    if (!c || !in || !out || !f || !cc || !rvec || !tvec) return fail(CCAL_E_ARG, "ccal map: NULL argument");
+    if (M < 0 || !(cs != 0.0)) return fail(CCAL_E_ARG, "ccal map: bad size / checker_size");
+    if (M == 0) return CCAL_OK;
+    HIPCHK(hipSetDevice(c->device));
+    DevBuf din, dout, dpar;
+    HIPCHK(hipMalloc(&din.p, sizeof(double) * in_w * (size_t)M));
+    HIPCHK(hipMalloc(&dout.p, sizeof(double) * out_w * (size_t)M));
+    HIPCHK(hipMalloc(&dpar.p, sizeof(double) * 12));
+    const double par[12] = {f[0], f[1], cc[0], cc[1], k, rvec[0], rvec[1], rvec[2], tvec[0], tvec[1], tvec[2], cs};
+    HIPCHK(hipMemcpyAsync(din.p, in, sizeof(double) * in_w * (size_t)M, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dpar.p, par, sizeof par, hipMemcpyHostToDevice, c->stream));
+    if (forward) HIPCHK(launch_map_forward(c->stream, (const double *)din.p, (double *)dout.p, M, (const double *)dpar.p));
+    else HIPCHK(launch_map_inverse(c->stream, (const double *)din.p, (double *)dout.p, M, (const double *)dpar.p));
+    HIPCHK(hipMemcpyAsync(out, dout.p, sizeof(double) * out_w * (size_t)M, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CCAL_OK;
+}
+
+int ccal_project(ccal_ctx *c, const double *xyz, int32_t M, const double f[2], const double cc[2], double k,
+                 const double rvec[3], const double tvec[3], double checker_size, double *rowcol) {
+    return map_common(c, xyz, M, 3, 2, f, cc, k, rvec, tvec, checker_size, rowcol, true);
+}
+
+int ccal_unproject(ccal_ctx *c, const double *rowcol, int32_t M, const double f[2], const double cc[2], double k,
+                   const double rvec[3], const double tvec[3], double checker_size, double *xyz) {
+    return map_common(c, rowcol, M, 2, 3, f, cc, k, rvec, tvec, checker_size, xyz, false);
+}
+
+int ccal_errors(ccal_ctx *c, int32_t N, int32_t n1, int32_t n2, const double *obj_scaled, const double *img,
+                const double f[2], const double cc[2], double k, const double *rvecs, const double *tvecs,
+                double checker_size, int32_t S, const double *inv_pts, double out[4]) {
+    if (!c || !obj_scaled || !img || !f || !cc || !rvecs || !tvecs || !out)
+        return fail(CCAL_E_ARG, "ccal_errors: NULL argument");
+    if (N < 1 || n1 < 2 || n2 < 2 || S < 0 || !(checker_size != 0.0)) return fail(CCAL_E_ARG, "ccal_errors: bad sizes");
+    const int P = n1 * n2;
+    if ((size_t)P * 24 > 60000) return fail(CCAL_E_ARG, "ccal_errors: board too large for the per-image LDS tile");
+    HIPCHK(hipSetDevice(c->device));
+    DevBuf dobj, dimg, dpar, drt, dinv, dpart;
+    HIPCHK(hipMalloc(&dobj.p, sizeof(double) * 3 * P));
+    HIPCHK(hipMalloc(&dimg.p, sizeof(double) * 2 * (size_t)P * N));
+    HIPCHK(hipMalloc(&dpar.p, sizeof(double) * 8));
+    HIPCHK(hipMalloc(&drt.p, sizeof(double) * 6 * (size_t)N));
+    HIPCHK(hipMalloc(&dpart.p, sizeof(double) * 4 * ((size_t)N + 1)));
+    std::vector<double> rt((size_t)6 * N);
+    for (int i = 0; i < N; i++)
+        for (int a = 0; a < 3; a++) { rt[(size_t)6 * i + a] = rvecs[(size_t)3 * i + a]; rt[(size_t)6 * i + 3 + a] = tvecs[(size_t)3 * i + a]; }
+    const double par[8] = {f[0], f[1], cc[0], cc[1], k, checker_size, 0, 0};
+    HIPCHK(hipMemcpyAsync(dobj.p, obj_scaled, sizeof(double) * 3 * P, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dimg.p, img, sizeof(double) * 2 * (size_t)P * N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dpar.p, par, sizeof par, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(drt.p, rt.data(), sizeof(double) * rt.size(), hipMemcpyHostToDevice, c->stream));
+    if (S > 0 && inv_pts) {
+        HIPCHK(hipMalloc(&dinv.p, sizeof(double) * 2 * (size_t)S * N));
+        HIPCHK(hipMemcpyAsync(dinv.p, inv_pts, sizeof(double) * 2 * (size_t)S * N, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(launch_errors(c->stream, (const double *)dobj.p, (const double *)dimg.p, (const double *)dpar.p,
+                         (const double *)drt.p, (const double *)dinv.p, (double *)dpart.p, N, n1, n2, S));
+    double sums[4];
+    HIPCHK(hipMemcpyAsync(sums, (double *)dpart.p + (size_t)4 * N, sizeof sums, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    // normalisation of src/buildcalibrations.jl:60-65
+    const double n = (double)P * N;
+    out[0] = std::sqrt(sums[0] / n);
+    out[1] = std::sqrt(sums[1] / n);
+    out[2] = std::sqrt(sums[2] / ((double)(n1 - 1) * (n2 - 1)) / N);
+    out[3] = (S > 0 && inv_pts) ? std::sqrt(sums[3] / S / N) : 0.0;
+    return CCAL_OK;
+}
+
+// ---- diagnostics -----------------------------------------------------------------------
+int ccal_debug_image_grams(ccal_ctx *c, const double intr[CCAL_NINTR], const double *rt_host, double *G_host) {
+    if (!c || !intr || !rt_host || !G_host) return fail(CCAL_E_ARG, "ccal_debug_image_grams: NULL argument");
+    if (!c->have_problem || !c->have_img) return fail(CCAL_E_STATE, "ccal_debug_image_grams: problem not set");
+    HIPCHK(hipSetDevice(c->device));
+    int rc = ccal_set_extrinsics(c, rt_host);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(c->d_ext, c->d_ext0, sizeof(double) * (size_t)c->N * EXT, hipMemcpyDeviceToDevice, c->stream));
+    if (!c->d_gram) HIPCHK(hipMalloc(&c->d_gram, sizeof(double) * c->n_cap * 256));
+    LmState &s = *c->h_st;
+    double keep[9];
+    memcpy(keep, c->intr0, sizeof keep);
+    memcpy(c->intr0, intr, sizeof keep);
+    host_state_defaults(c, s);
+    memcpy(c->intr0, keep, sizeof keep);
+    for (int a = 0; a < 9; a++) s.intr_prev[a] = intr[a];
+    HIPCHK(hipMemcpyAsync(c->d_st_scratch, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_ext, c->d_blk, c->d_st_scratch, c->d_partials,
+                           c->d_gram, c->N, c->P));
+    HIPCHK(hipMemcpyAsync(G_host, c->d_gram, sizeof(double) * (size_t)c->N * 256, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CCAL_OK;
+}
+
+int ccal_time_sweep(ccal_ctx *c, int32_t reps, double *avg_us) {
+    if (!c || !avg_us || reps < 1) return fail(CCAL_E_ARG, "ccal_time_sweep: bad argument");
+    if (!c->have_problem || !c->have_img || !c->have_intr || !c->have_ext)
+        return fail(CCAL_E_STATE, "ccal_time_sweep: needs image points and a parameter point");
+    HIPCHK(hipSetDevice(c->device));
+    LmState s;
+    host_state_defaults(c, s);
+    if (c->have_result) {
+        for (int a = 0; a < 9; a++) s.intr_prev[a] = c->h_st->intr_prev[a];
+        s.parity = c->h_st->parity;
+    } else {
+        for (int a = 0; a < 9; a++) s.intr_prev[a] = c->intr0[a];
+        HIPCHK(hipMemcpyAsync(c->d_ext, c->d_ext0, sizeof(double) * (size_t)c->N * EXT, hipMemcpyDeviceToDevice,
+                              c->stream));
+    }
+    HIPCHK(hipMemcpyAsync(c->d_st_scratch, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    for (int w = 0; w < 3; w++)
+        HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_ext, c->d_blk, c->d_st_scratch, c->d_partials,
+                               nullptr, c->N, c->P));
+    HIPCHK(hipEventRecord(e0, c->stream));
+    for (int r = 0; r < reps; r++)
+        HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_ext, c->d_blk, c->d_st_scratch, c->d_partials,
+                               nullptr, c->N, c->P));
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *avg_us = 1000.0 * ms / reps;
+    return CCAL_OK;
+}
+
+}  // extern "C"

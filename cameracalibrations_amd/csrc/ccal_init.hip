@@ -1,0 +1,620 @@
+// ccal_init.hip -- closed-form initialisation of calibrateCamera on gfx950.
+//
+// What OpenCV does before its LM loop, behind the reference's call at src/detect_fit.jl:47
+// (the reference passes no intrinsic guess, src/detect_fit.jl:40, so both stages always run):
+//   A4  cvInitIntrinsicParams2D : per-image homography board -> image, focal lengths from the
+//       orthogonality constraints of its columns
+//   A5  cvFindExtrinsicCameraParams2, planar branch: homography on normalised points,
+//       decomposition, orthonormalisation, 6-parameter LM polish
+//
+// Mapping: ONE 64-lane workgroup (= one wavefront) per image, one lane per corner; sums over
+// corners go through the LDS-staged f64 MFMA Gram of ccal_wave.hpp or wave butterflies; the
+// small dense algebra (9x9 inverse iteration, 8x8 / 6x6 Cholesky, 3x3 polar) is wave-uniform
+// register arithmetic.  Per-image iteration counts differ, hence one wave per workgroup.
+#include <hip/hip_runtime.h>
+
+#include "ccal_kernels.hpp"
+#include "ccal_math.hpp"
+#include "ccal_state.hpp"
+#include "ccal_wave.hpp"
+
+namespace ccal {
+
+constexpr double DBL_EPS = 2.220446049250313e-16;
+constexpr double FLT_EPS = 1.1920928955078125e-07;
+
+// ---------------------------------------------------------------------------------------
+// point sources: (model xy, observed xy), both rounded to float32 as findHomography does
+// ---------------------------------------------------------------------------------------
+struct RawPoints {               // A4: board template xy -> pixel coordinates
+    const float *obj;            // [3,P]
+    const float2 *img;           // this image's [P]
+    __device__ __forceinline__ void get(int p, double &Mx, double &My, double &mx, double &my) const {
+        Mx = (double)obj[3 * p]; My = (double)obj[3 * p + 1];
+        const float2 uv = img[p];
+        mx = (double)uv.x; my = (double)uv.y;
+    }
+};
+
+struct NormPoints {              // A5: centred template xy -> normalised (undistorted) image coordinates
+    const float *obj;
+    const float2 *img;
+    double cMx, cMy;             // template centroid
+    double in[NINTR];
+    bool distorted;
+    __device__ __forceinline__ void get(int p, double &Mx, double &My, double &mx, double &my) const {
+        Mx = (double)(float)((double)obj[3 * p] - cMx);
+        My = (double)(float)((double)obj[3 * p + 1] - cMy);
+        const float2 uv = img[p];
+        double x = ((double)uv.x - in[2]) / in[0], y = ((double)uv.y - in[3]) / in[1];
+        if (distorted) {         // [OCV-K cvUndistortPoints]: 5 fixed-point iterations
+            const double x0 = x, y0 = y;
+            for (int j = 0; j < 5; j++) {
+                const double r2 = x * x + y * y;
+                const double icd = 1.0 / (1.0 + ((in[8] * r2 + in[5]) * r2 + in[4]) * r2);
+                if (icd < 0.0) { x = x0; y = y0; break; }
+                const double dx = 2.0 * in[6] * x * y + in[7] * (r2 + 2.0 * x * x);
+                const double dy = in[6] * (r2 + 2.0 * y * y) + 2.0 * in[7] * x * y;
+                x = (x0 - dx) * icd; y = (y0 - dy) * icd;
+            }
+        }
+        mx = (double)(float)x; my = (double)(float)y;
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// homography residual (+ Jacobian rows) of one correspondence, h[8] = 1
+// [OCV-K HomographyRefineCallback::compute]
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void homog_point(const double h[8], double Mx, double My, double mx, double my,
+                                            double &eu, double &ev, double &ww, double &xi, double &yi) {
+    ww = h[6] * Mx + h[7] * My + 1.0;
+    ww = fabs(ww) > DBL_EPS ? 1.0 / ww : 0.0;
+    xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
+    yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+    eu = xi - mx;
+    ev = yi - my;
+}
+
+template <class Pts>
+__device__ double homog_error(const Pts &pts, int P, int lane, const double h[8], double &rmax) {
+    double s = 0.0, m = 0.0;
+    for (int c0 = 0; c0 < P; c0 += 64) {
+        const int p = c0 + lane;
+        if (p < P) {
+            double Mx, My, mx, my, eu, ev, ww, xi, yi;
+            pts.get(p, Mx, My, mx, my);
+            homog_point(h, Mx, My, mx, my, eu, ev, ww, xi, yi);
+            s += eu * eu + ev * ev;
+            m = fmax(m, fmax(fabs(eu), fabs(ev)));
+        }
+    }
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) m = fmax(m, __shfl_xor(m, k, 64));
+    rmax = m;
+    return wave_sum(s);
+}
+
+// A (8x8 packed lower) = J^T J, v = J^T r, S = r^T r at h, via the MFMA Gram (columns 0-7 J, 8 r)
+template <class Pts>
+__device__ void homog_normal_eq(const Pts &pts, int P, int lane, const double h[8], double *tile, double *Gs,
+                                double A[36], double v[8], double &S) {
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int c0 = 0; c0 < P; c0 += 64) {
+        const int p = c0 + lane;
+        const bool valid = p < P;
+        double Mx, My, mx, my, eu, ev, ww, xi, yi;
+        pts.get(valid ? p : P - 1, Mx, My, mx, my);
+        homog_point(h, Mx, My, mx, my, eu, ev, ww, xi, yi);
+        double mu[16], mv[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) { mu[c] = 0.0; mv[c] = 0.0; }
+        mu[0] = Mx * ww; mu[1] = My * ww; mu[2] = ww; mu[6] = -Mx * ww * xi; mu[7] = -My * ww * xi; mu[8] = eu;
+        mv[3] = Mx * ww; mv[4] = My * ww; mv[5] = ww; mv[6] = -Mx * ww * yi; mv[7] = -My * ww * yi; mv[8] = ev;
+        tile_store_rows(tile, lane, mu, mv, valid);
+        __syncthreads();
+        tile_gram(tile, lane, min(64, P - c0), acc0, acc1);
+        __syncthreads();
+    }
+    gram_to_lds(Gs, lane, acc0, acc1);
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 8; a++) {
+#pragma unroll
+        for (int b = 0; b <= a; b++) A[tri(a, b)] = Gs[a * 16 + b];
+        v[a] = Gs[a * 16 + 8];
+    }
+    S = Gs[8 * 16 + 8];
+    __syncthreads();
+}
+
+// [OCV-K LMSolverImpl::run] with maxIters = 10, eps = FLT_EPSILON on the 8 free entries
+template <class Pts>
+__device__ void homog_refine(const Pts &pts, int P, int lane, double *tile, double *Gs, double x[8]) {
+    double A[36], v[8], D[8], S;
+    homog_normal_eq(pts, P, lane, x, tile, Gs, A, v, S);
+#pragma unroll
+    for (int a = 0; a < 8; a++) D[a] = A[tri(a, a)];
+    const double Rlo = 0.25, Rhi = 0.75;
+    double lambda = 1.0, lc = 0.75;
+    double rmax;
+    (void)homog_error(pts, P, lane, x, rmax);
+    for (int iter = 0;;) {
+        double Ap[36], d[8], xd[8];
+#pragma unroll
+        for (int k = 0; k < 36; k++) Ap[k] = A[k];
+#pragma unroll
+        for (int a = 0; a < 8; a++) { Ap[tri(a, a)] += lambda * D[a]; d[a] = v[a]; }
+        if (!chol_packed<8>(Ap)) break;                 // degenerate normal equations: keep the current H
+        fwd_subst<8>(Ap, d);
+        bwd_subst<8>(Ap, d);
+#pragma unroll
+        for (int a = 0; a < 8; a++) xd[a] = x[a] - d[a];
+        double rdmax;
+        const double Sd = homog_error(pts, P, lane, xd, rdmax);
+        double dS = 0.0, dv = 0.0, dmax = 0.0;          // dS = d . (2 v - A d)
+#pragma unroll
+        for (int a = 0; a < 8; a++) {
+            double Ad = 0.0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) Ad += A[a >= b ? tri(a, b) : tri(b, a)] * d[b];
+            dS += d[a] * (2.0 * v[a] - Ad);
+            dv += d[a] * v[a];
+            dmax = fmax(dmax, fabs(d[a]));
+        }
+        const double Rr = (S - Sd) / (fabs(dS) > DBL_EPS ? dS : 1.0);
+        if (Rr > Rhi) {
+            lambda *= 0.5;
+            if (lambda < lc) lambda = 0.0;
+        } else if (Rr < Rlo) {
+            double nu = (Sd - S) / (fabs(dv) > DBL_EPS ? dv : 1.0) + 2.0;
+            nu = nu < 2.0 ? 2.0 : (nu > 10.0 ? 10.0 : nu);
+            if (lambda == 0.0) {
+                // lambda = lc = 1 / max |diag(A^-1)|;  diag(A^-1)[a] = || L^-1 e_a ||^2
+                double L[36];
+#pragma unroll
+                for (int k = 0; k < 36; k++) L[k] = A[k];
+                double maxval = DBL_EPS;
+                if (chol_packed<8>(L)) {
+#pragma unroll
+                    for (int a = 0; a < 8; a++) {
+                        double e[8];
+#pragma unroll
+                        for (int b = 0; b < 8; b++) e[b] = (a == b) ? 1.0 : 0.0;
+                        fwd_subst<8>(L, e);
+                        double s2 = 0.0;
+#pragma unroll
+                        for (int b = 0; b < 8; b++) s2 += e[b] * e[b];
+                        maxval = fmax(maxval, s2);
+                    }
+                }
+                lambda = lc = 1.0 / maxval;
+                nu *= 0.5;
+            }
+            lambda *= nu;
+        }
+        if (Sd < S) {
+#pragma unroll
+            for (int a = 0; a < 8; a++) x[a] = xd[a];
+            homog_normal_eq(pts, P, lane, x, tile, Gs, A, v, S);
+            rmax = rdmax;
+        }
+        iter++;
+        if (!(iter < 10 && dmax >= FLT_EPS && rmax >= FLT_EPS)) break;
+    }
+}
+
+// [OCV-K findHomography(method 0)]: per-axis normalised DLT (smallest eigenvector of LtL by
+// shifted inverse iteration) + LM polish.  Every lane returns the same H.  false = degenerate.
+template <class Pts>
+__device__ bool wave_homography(const Pts &pts, int P, int lane, double *tile, double *Gs, double H[9]) {
+    double cM0 = 0, cM1 = 0, cm0 = 0, cm1 = 0;
+    for (int c0 = 0; c0 < P; c0 += 64) {
+        const int p = c0 + lane;
+        if (p < P) {
+            double Mx, My, mx, my;
+            pts.get(p, Mx, My, mx, my);
+            cM0 += Mx; cM1 += My; cm0 += mx; cm1 += my;
+        }
+    }
+    cM0 = wave_sum(cM0) / P; cM1 = wave_sum(cM1) / P; cm0 = wave_sum(cm0) / P; cm1 = wave_sum(cm1) / P;
+    double sM0 = 0, sM1 = 0, sm0 = 0, sm1 = 0;
+    for (int c0 = 0; c0 < P; c0 += 64) {
+        const int p = c0 + lane;
+        if (p < P) {
+            double Mx, My, mx, my;
+            pts.get(p, Mx, My, mx, my);
+            sM0 += fabs(Mx - cM0); sM1 += fabs(My - cM1); sm0 += fabs(mx - cm0); sm1 += fabs(my - cm1);
+        }
+    }
+    sM0 = wave_sum(sM0); sM1 = wave_sum(sM1); sm0 = wave_sum(sm0); sm1 = wave_sum(sm1);
+    if (fabs(sm0) < DBL_EPS || fabs(sm1) < DBL_EPS || fabs(sM0) < DBL_EPS || fabs(sM1) < DBL_EPS) return false;
+    sm0 = P / sm0; sm1 = P / sm1; sM0 = P / sM0; sM1 = P / sM1;
+
+    // LtL = sum Lx Lx^T + Ly Ly^T through the MFMA Gram (9 of 16 columns used)
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int c0 = 0; c0 < P; c0 += 64) {
+        const int p = c0 + lane;
+        const bool valid = p < P;
+        double Mx, My, mx, my;
+        pts.get(valid ? p : P - 1, Mx, My, mx, my);
+        const double x = (mx - cm0) * sm0, y = (my - cm1) * sm1;
+        const double X = (Mx - cM0) * sM0, Y = (My - cM1) * sM1;
+        double mu[16], mv[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) { mu[c] = 0.0; mv[c] = 0.0; }
+        mu[0] = X; mu[1] = Y; mu[2] = 1.0; mu[6] = -x * X; mu[7] = -x * Y; mu[8] = -x;
+        mv[3] = X; mv[4] = Y; mv[5] = 1.0; mv[6] = -y * X; mv[7] = -y * Y; mv[8] = -y;
+        tile_store_rows(tile, lane, mu, mv, valid);
+        __syncthreads();
+        tile_gram(tile, lane, min(64, P - c0), acc0, acc1);
+        __syncthreads();
+    }
+    gram_to_lds(Gs, lane, acc0, acc1);
+    __syncthreads();
+    double A[45], trace = 0.0;
+#pragma unroll
+    for (int a = 0; a < 9; a++) {
+#pragma unroll
+        for (int b = 0; b <= a; b++) A[tri(a, b)] = Gs[a * 16 + b];
+        trace += A[tri(a, a)];
+    }
+    __syncthreads();
+    // smallest eigenvector: inverse iteration on LtL + mu I (mu keeps the factor positive
+    // definite for noise-free data, where the smallest eigenvalue is 0 up to rounding)
+    const double mu_shift = 1e-11 * trace;
+#pragma unroll
+    for (int a = 0; a < 9; a++) A[tri(a, a)] += mu_shift;
+    if (!chol_packed<9>(A)) return false;
+    double hv[9];
+#pragma unroll
+    for (int a = 0; a < 9; a++) hv[a] = 1.0 / 3.0;
+    for (int it = 0; it < 12; it++) {
+        fwd_subst<9>(A, hv);
+        bwd_subst<9>(A, hv);
+        double nrm = 0.0;
+#pragma unroll
+        for (int a = 0; a < 9; a++) nrm += hv[a] * hv[a];
+        nrm = 1.0 / sqrt(nrm);
+#pragma unroll
+        for (int a = 0; a < 9; a++) hv[a] *= nrm;
+    }
+    // H = invHnorm * H0 * Hnorm2, scaled so that H[8] = 1
+    const double i0 = 1.0 / sm0, i1 = 1.0 / sm1;
+    double T[9];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        T[j] = i0 * hv[j] + cm0 * hv[6 + j];
+        T[3 + j] = i1 * hv[3 + j] + cm1 * hv[6 + j];
+        T[6 + j] = hv[6 + j];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        H[a * 3] = T[a * 3] * sM0;
+        H[a * 3 + 1] = T[a * 3 + 1] * sM1;
+        H[a * 3 + 2] = -T[a * 3] * cM0 * sM0 - T[a * 3 + 1] * cM1 * sM1 + T[a * 3 + 2];
+    }
+    const double s = 1.0 / H[8];
+#pragma unroll
+    for (int k = 0; k < 9; k++) H[k] *= s;
+    if (P > 4) {
+        homog_refine(pts, P, lane, tile, Gs, H);
+        H[8] = 1.0;
+    }
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 9; k++) finite = finite && (fabs(H[k]) < 1.0e300);
+    return finite;
+}
+
+// ---------------------------------------------------------------------------------------
+// A4: homography per image + its two rows of the focal-length least squares
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_init_homography(const float *__restrict__ obj, const float *__restrict__ img,
+                                                         double *__restrict__ H_out, double *__restrict__ foc, int N,
+                                                         int P, int width, int height) {
+    __shared__ __attribute__((aligned(16))) double s_tile[TILE_D];
+    __shared__ __attribute__((aligned(16))) double s_G[256];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    RawPoints pts{obj, reinterpret_cast<const float2 *>(img) + (size_t)i * P};
+    double H[9];
+    const bool ok = wave_homography(pts, P, lane, s_tile, s_G, H);
+    if (lane < 9) H_out[(size_t)9 * i + lane] = ok ? H[lane] : 0.0;
+    // [OCV-K cvInitIntrinsicParams2D]
+    const double a2 = !width ? 0.5 : (width - 1) * 0.5, a5 = !height ? 0.5 : (height - 1) * 0.5;
+    H[0] -= H[6] * a2; H[1] -= H[7] * a2; H[2] -= H[8] * a2;
+    H[3] -= H[6] * a5; H[4] -= H[7] * a5; H[5] -= H[8] * a5;
+    double hh[3], vv[3], d1[3], d2[3], n[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const double t0 = H[j * 3], t1 = H[j * 3 + 1];
+        hh[j] = t0; vv[j] = t1; d1[j] = (t0 + t1) * 0.5; d2[j] = (t0 - t1) * 0.5;
+        n[0] += t0 * t0; n[1] += t1 * t1; n[2] += d1[j] * d1[j]; n[3] += d2[j] * d2[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) n[j] = 1.0 / sqrt(n[j]);
+#pragma unroll
+    for (int j = 0; j < 3; j++) { hh[j] *= n[0]; vv[j] *= n[1]; d1[j] *= n[2]; d2[j] *= n[3]; }
+    const double Ap[4] = {hh[0] * vv[0], hh[1] * vv[1], d1[0] * d2[0], d1[1] * d2[1]};
+    const double bp[2] = {-hh[2] * vv[2], -d1[2] * d2[2]};
+    double out[NFOC];
+    out[0] = Ap[0] * Ap[0] + Ap[2] * Ap[2];
+    out[1] = Ap[0] * Ap[1] + Ap[2] * Ap[3];
+    out[2] = Ap[1] * Ap[1] + Ap[3] * Ap[3];
+    out[3] = Ap[0] * bp[0] + Ap[2] * bp[1];
+    out[4] = Ap[1] * bp[0] + Ap[3] * bp[1];
+    out[5] = ok ? 0.0 : 1.0;
+    out[6] = out[7] = 0.0;
+    if (!ok) { out[0] = out[1] = out[2] = out[3] = out[4] = 0.0; }
+    if (lane < NFOC) {
+        double v = out[0];
+#pragma unroll
+        for (int k = 1; k < NFOC; k++) v = (lane == k) ? out[k] : v;
+        foc[(size_t)NFOC * i + lane] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_init_focal_reduce(const double *__restrict__ foc, double *__restrict__ red,
+                                                           int N) {
+    const int j = threadIdx.x;
+    if (j >= NFOC) return;
+    double s = 0.0;
+    for (int i = 0; i < N; i++) s += foc[(size_t)NFOC * i + j];    // fixed order
+    red[j] = s;
+}
+
+__global__ __launch_bounds__(64) void k_init_focal_solve(const double *__restrict__ red, LmState *st, int width,
+                                                          int height, double aspect) {
+    if (threadIdx.x != 0) return;
+    // cvSolve(A, b, f, CV_NORMAL + CV_SVD): 2x2 normal equations
+    double A[3] = {red[0], red[1], red[2]}, f[2] = {red[3], red[4]};
+    int status = red[5] > 0.0 ? -3 : 0;
+    if (chol_packed<2>(A)) {
+        fwd_subst<2>(A, f);
+        bwd_subst<2>(A, f);
+    } else {
+        status = -3;
+    }
+    double fx = sqrt(fabs(1.0 / f[0])), fy = sqrt(fabs(1.0 / f[1]));
+    if (aspect != 0.0) {
+        const double tf = (fx + fy) / (aspect + 1.0);
+        fx = aspect * tf;
+        fy = tf;
+    }
+    st->intr_prev[0] = fx;
+    st->intr_prev[1] = fy;
+    st->intr_prev[2] = !width ? 0.5 : (width - 1) * 0.5;
+    st->intr_prev[3] = !height ? 0.5 : (height - 1) * 0.5;
+    for (int a = 4; a < 9; a++) st->intr_prev[a] = 0.0;
+    st->status = status;
+}
+
+// ---------------------------------------------------------------------------------------
+// A5: planar pose from the homography on normalised points + 6-parameter LM polish
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void polar3(double X[9]) {
+    // orthogonal polar factor (== U V^T of the SVD) by Newton iteration X <- (X + X^-T) / 2
+    for (int it = 0; it < 10; it++) {
+        const double c0 = X[4] * X[8] - X[5] * X[7], c1 = X[5] * X[6] - X[3] * X[8], c2 = X[3] * X[7] - X[4] * X[6];
+        const double c3 = X[2] * X[7] - X[1] * X[8], c4 = X[0] * X[8] - X[2] * X[6], c5 = X[1] * X[6] - X[0] * X[7];
+        const double c6 = X[1] * X[5] - X[2] * X[4], c7 = X[2] * X[3] - X[0] * X[5], c8 = X[0] * X[4] - X[1] * X[3];
+        const double idet = 1.0 / (X[0] * c0 + X[1] * c1 + X[2] * c2);
+        const double C[9] = {c0, c1, c2, c3, c4, c5, c6, c7, c8};   // cofactors: X^-T = C / det
+#pragma unroll
+        for (int k = 0; k < 9; k++) X[k] = 0.5 * (X[k] + C[k] * idet);
+    }
+}
+
+__device__ __forceinline__ void rodrigues_inv(const double R[9], double r[3]) {
+    // [OCV-K cvRodrigues2, matrix -> vector] for an orthonormal R
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1.0) * 0.5;
+    c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+    double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0.0) { r[0] = r[1] = r[2] = 0.0; return; }
+        double t;
+        t = (R[0] + 1.0) * 0.5; r[0] = sqrt(fmax(t, 0.0));
+        t = (R[4] + 1.0) * 0.5; r[1] = sqrt(fmax(t, 0.0)) * (R[1] < 0.0 ? -1.0 : 1.0);
+        t = (R[8] + 1.0) * 0.5; r[2] = sqrt(fmax(t, 0.0)) * (R[2] < 0.0 ? -1.0 : 1.0);
+        if (fabs(r[0]) < fabs(r[1]) && fabs(r[0]) < fabs(r[2]) && ((R[5] > 0.0) != (r[1] * r[2] > 0.0))) r[2] = -r[2];
+        theta /= sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        r[0] *= theta; r[1] *= theta; r[2] *= theta;
+        return;
+    }
+    const double vth = theta / (2.0 * s);
+    r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
+}
+
+// residual-only / residual+Jacobian pass of the per-view LM
+__device__ double view_error(const float *obj, const float2 *img, int P, int lane, const double rt[6],
+                             const double in[NINTR]) {
+    double R[9];
+    rodrigues_R(rt, R);
+    double s = 0.0;
+    for (int c0 = 0; c0 < P; c0 += 64) {
+        const int p = c0 + lane;
+        if (p < P) {
+            const double M[3] = {(double)obj[3 * p], (double)obj[3 * p + 1], (double)obj[3 * p + 2]};
+            const float2 uv = img[p];
+            double eu, ev;
+            point_residual(M, (double)uv.x, (double)uv.y, R, rt + 3, in, eu, ev);
+            s += eu * eu + ev * ev;
+        }
+    }
+    return wave_sum(s);
+}
+
+__device__ double view_normal_eq(const float *obj, const float2 *img, int P, int lane, const double rt[6],
+                                 const double in[NINTR], double *tile, double *Gs, double JtJ[21], double JtErr[6]) {
+    double R[9], dR[27];
+    rodrigues(rt, R, dR);
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int c0 = 0; c0 < P; c0 += 64) {
+        const int p = c0 + lane;
+        const bool valid = p < P;
+        const int pc = valid ? p : P - 1;
+        const double M[3] = {(double)obj[3 * pc], (double)obj[3 * pc + 1], (double)obj[3 * pc + 2]};
+        const float2 uv = img[pc];
+        double mu[NCOL], mv[NCOL];
+        point_rows(M, (double)uv.x, (double)uv.y, R, dR, rt + 3, in, 0.0, mu, mv);
+        tile_store_rows(tile, lane, mu, mv, valid);
+        __syncthreads();
+        tile_gram(tile, lane, min(64, P - c0), acc0, acc1);
+        __syncthreads();
+    }
+    gram_to_lds(Gs, lane, acc0, acc1);
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int b = 0; b <= a; b++) JtJ[tri(a, b)] = Gs[a * 16 + b];
+        JtErr[a] = Gs[a * 16 + COL_E];
+    }
+    const double e2 = Gs[COL_E * 16 + COL_E];
+    __syncthreads();
+    return e2;
+}
+
+__global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict__ obj, const float *__restrict__ img,
+                                                         const LmState *__restrict__ st, double *__restrict__ ext,
+                                                         int *__restrict__ fail_count, int N, int P) {
+    __shared__ __attribute__((aligned(16))) double s_tile[TILE_D];
+    __shared__ __attribute__((aligned(16))) double s_G[256];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const float2 *img_i = reinterpret_cast<const float2 *>(img) + (size_t)i * P;
+
+    NormPoints pts;
+    pts.obj = obj;
+    pts.img = img_i;
+    bool distorted = false;
+#pragma unroll
+    for (int a = 0; a < NINTR; a++) {
+        pts.in[a] = st->intr_prev[a];
+        if (a >= 4 && pts.in[a] != 0.0) distorted = true;
+    }
+    pts.distorted = distorted;
+    // template centroid (R_transform = I for a z = 0 board: T_transform = -Mc)
+    double c0s = 0.0, c1s = 0.0;
+    for (int c0 = 0; c0 < P; c0 += 64) {
+        const int p = c0 + lane;
+        if (p < P) { c0s += (double)obj[3 * p]; c1s += (double)obj[3 * p + 1]; }
+    }
+    pts.cMx = wave_sum(c0s) / P;
+    pts.cMy = wave_sum(c1s) / P;
+
+    double H[9], rt[6];
+    const bool ok = wave_homography(pts, P, lane, s_tile, s_G, H);
+    if (ok) {
+        double h1[3] = {H[0], H[3], H[6]}, h2[3] = {H[1], H[4], H[7]}, h3[3] = {H[2], H[5], H[8]};
+        const double n1 = sqrt(h1[0] * h1[0] + h1[1] * h1[1] + h1[2] * h1[2]);
+        const double n2 = sqrt(h2[0] * h2[0] + h2[1] * h2[1] + h2[2] * h2[2]);
+        double tt[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            h1[a] /= fmax(n1, DBL_EPS);
+            h2[a] /= fmax(n2, DBL_EPS);
+            tt[a] = h3[a] * 2.0 / fmax(n1 + n2, DBL_EPS);
+        }
+        h3[0] = h1[1] * h2[2] - h1[2] * h2[1];
+        h3[1] = h1[2] * h2[0] - h1[0] * h2[2];
+        h3[2] = h1[0] * h2[1] - h1[1] * h2[0];
+        double Rm[9] = {h1[0], h2[0], h3[0], h1[1], h2[1], h3[1], h1[2], h2[2], h3[2]};
+        polar3(Rm);
+        rodrigues_inv(Rm, rt);
+        double R[9];
+        rodrigues_R(rt, R);
+        // t += R * T_transform,  T_transform = -(cMx, cMy, 0)
+#pragma unroll
+        for (int a = 0; a < 3; a++) rt[3 + a] = tt[a] - (R[a * 3] * pts.cMx + R[a * 3 + 1] * pts.cMy);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) rt[k] = 0.0;
+        if (lane == 0) atomicAdd(fail_count, 1);
+    }
+
+    // ---- [OCV-K CvLevMarq(6, 2P, (COUNT+EPS, 20, FLT_EPSILON))::update] ----
+    double prev[6], JtJ[21], JtErr[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { prev[k] = rt[k]; JtErr[k] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 21; k++) JtJ[k] = 0.0;
+    int lambdaLg10 = -3, iters = 0, state = 1;   // 1 STARTED, 2 CALC_J, 3 CHECK_ERR
+    double errNorm = 0.0, prevErrNorm = 0.0;
+    const double *in = pts.in;
+    for (int guard = 0; ok && guard < 20 * 24; guard++) {
+        bool do_step = false;
+        if (state == 1) {
+            state = 2;
+        } else if (state == 2) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) prev[k] = rt[k];
+            do_step = true;
+            prevErrNorm = errNorm;
+            state = 3;
+        } else {
+            if (errNorm > prevErrNorm && ++lambdaLg10 <= 16) {
+                do_step = true;
+            } else {
+                lambdaLg10 = max(lambdaLg10 - 1, -16);
+                double num = 0.0, den = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) { num += (rt[k] - prev[k]) * (rt[k] - prev[k]); den += prev[k] * prev[k]; }
+                if (++iters >= 20 || sqrt(num) / sqrt(den) < FLT_EPS) break;
+                prevErrNorm = errNorm;
+                state = 2;
+            }
+        }
+        if (do_step) {
+            // CvLevMarq::step: diag *= 1 + lambda; solve; param = prev - delta
+            double A[21], d[6];
+#pragma unroll
+            for (int k = 0; k < 21; k++) A[k] = JtJ[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) d[k] = JtErr[k];
+            damp_diag<6>(A, exp((double)lambdaLg10 * log(10.0)));
+            const bool pd = chol_packed<6>(A);
+            fwd_subst<6>(A, d);
+            bwd_subst<6>(A, d);
+#pragma unroll
+            for (int k = 0; k < 6; k++) rt[k] = prev[k] - (pd ? d[k] : 0.0);
+        }
+        if (state == 2) errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, in, s_tile, s_G, JtJ, JtErr));
+        else errNorm = sqrt(view_error(obj, img_i, P, lane, rt, in));
+    }
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 6; k++) finite = finite && (fabs(rt[k]) < 1.0e300);
+    if (ok && !finite && lane == 0) atomicAdd(fail_count, 1);
+    if (lane < 6) {
+        double v = rt[0];
+#pragma unroll
+        for (int k = 1; k < 6; k++) v = (lane == k) ? rt[k] : v;
+        ext[(size_t)i * EXT + lane] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+hipError_t launch_init_homography(hipStream_t stream, const float *obj, const float *img, double *H_out,
+                                  double *foc_partials, int N, int P, int width, int height) {
+    hipLaunchKernelGGL(k_init_homography, dim3(N), dim3(64), 0, stream, obj, img, H_out, foc_partials, N, P, width,
+                       height);
+    return hipGetLastError();
+}
+hipError_t launch_init_focal_reduce(hipStream_t stream, const double *foc_partials, double *foc_red, int N) {
+    hipLaunchKernelGGL(k_init_focal_reduce, dim3(1), dim3(64), 0, stream, foc_partials, foc_red, N);
+    return hipGetLastError();
+}
+hipError_t launch_init_focal_solve(hipStream_t stream, const double *foc_red, LmState *st, int width, int height,
+                                   double aspect) {
+    hipLaunchKernelGGL(k_init_focal_solve, dim3(1), dim3(64), 0, stream, foc_red, st, width, height, aspect);
+    return hipGetLastError();
+}
+hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const float *img, const LmState *st,
+                                  double *ext, int *fail_count, int N, int P) {
+    hipLaunchKernelGGL(k_init_extrinsics, dim3(N), dim3(64), 0, stream, obj, img, st, ext, fail_count, N, P);
+    return hipGetLastError();
+}
+
+}  // namespace ccal

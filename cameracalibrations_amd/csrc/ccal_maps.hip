@@ -1,0 +1,142 @@
+// ccal_maps.hip -- RowCol <-> XYZ point maps and the four RMS error metrics on gfx950.
+//
+// Batched forms of the reference's per-point closures:
+//   real2image[i]  src/meta.jl:27-33,39-44,88   + obj2img  src/buildcalibrations.jl:1-6
+//   image2real[i]  src/meta.jl:50-76,82         (closed-form cubic instead of Polynomials.roots)
+//   calculate_errors  src/buildcalibrations.jl:28-31,37-67
+// All FP64; one lane per point, coalesced [3,M] / [2,M] streams.
+#include <hip/hip_runtime.h>
+
+#include "ccal_kernels.hpp"
+#include "ccal_math.hpp"
+
+namespace ccal {
+
+// par = f0 f1 c0 c1 k r0 r1 r2 t0 t1 t2 checker_size
+__global__ __launch_bounds__(256) void k_map_forward(const double *__restrict__ xyz, double *__restrict__ rc, int M,
+                                                      const double *__restrict__ par) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const double f[2] = {par[0], par[1]}, c[2] = {par[2], par[3]};
+    const double r[3] = {par[5], par[6], par[7]}, t[3] = {par[8], par[9], par[10]};
+    double R[9];
+    rodrigues_R(r, R);
+    const double p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    double o[2];
+    map_forward(p, f, c, par[4], R, t, 1.0 / par[11], o);
+    rc[2 * i] = o[0];
+    rc[2 * i + 1] = o[1];
+}
+
+__global__ __launch_bounds__(256) void k_map_inverse(const double *__restrict__ rc, double *__restrict__ xyz, int M,
+                                                      const double *__restrict__ par) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    const double f[2] = {par[0], par[1]}, c[2] = {par[2], par[3]};
+    const double r[3] = {par[5], par[6], par[7]}, t[3] = {par[8], par[9], par[10]};
+    double R[9], ti[3];
+    rodrigues_R(r, R);
+#pragma unroll
+    for (int a = 0; a < 3; a++) ti[a] = -(R[a] * t[0] + R[3 + a] * t[1] + R[6 + a] * t[2]);
+    const double q[2] = {rc[2 * i], rc[2 * i + 1]};
+    double o[3];
+    map_inverse(q, f, c, par[4], R, ti, par[11], o);
+    xyz[3 * i] = o[0];
+    xyz[3 * i + 1] = o[1];
+    xyz[3 * i + 2] = o[2];
+}
+
+// One workgroup per image: the four sums of calculate_errors for that image.
+// par = f0 f1 c0 c1 k checker_size;  rt [6,N];  partials [4,N]
+__global__ __launch_bounds__(256) void k_errors(const double *__restrict__ obj, const double *__restrict__ img,
+                                                 const double *__restrict__ par, const double *__restrict__ rt,
+                                                 const double *__restrict__ inv_pts, double *__restrict__ partials,
+                                                 int n1, int n2, int S) {
+    extern __shared__ __attribute__((aligned(16))) double s_xyz[];   // [3,P] projected corners
+    __shared__ double s_acc[4][256];
+    const int i = blockIdx.x, tid = threadIdx.x, P = n1 * n2;
+    const double f[2] = {par[0], par[1]}, c[2] = {par[2], par[3]}, k = par[4], cs = par[5];
+    const double r[3] = {rt[6 * i], rt[6 * i + 1], rt[6 * i + 2]};
+    const double t[3] = {rt[6 * i + 3], rt[6 * i + 4], rt[6 * i + 5]};
+    double R[9], ti[3];
+    rodrigues_R(r, R);
+#pragma unroll
+    for (int a = 0; a < 3; a++) ti[a] = -(R[a] * t[0] + R[3 + a] * t[1] + R[6 + a] * t[2]);
+    double reproj = 0.0, proj = 0.0, dist = 0.0, inv = 0.0;
+    const double *mi = img + (size_t)2 * P * i;
+    for (int p = tid; p < P; p += 256) {
+        const double o[3] = {obj[3 * p], obj[3 * p + 1], obj[3 * p + 2]};
+        const double m[2] = {mi[2 * p], mi[2 * p + 1]};
+        double rc[2], x[3];
+        map_forward(o, f, c, k, R, t, 1.0 / cs, rc);                       // _reprojection, :28-31
+        reproj += (rc[0] - m[0]) * (rc[0] - m[0]) + (rc[1] - m[1]) * (rc[1] - m[1]);
+        map_inverse(m, f, c, k, R, ti, cs, x);                             // projected = c.(imgpoints, i), :46
+        proj += (x[0] - o[0]) * (x[0] - o[0]) + (x[1] - o[1]) * (x[1] - o[1]) + (x[2] - o[2]) * (x[2] - o[2]);
+        s_xyz[3 * p] = x[0]; s_xyz[3 * p + 1] = x[1]; s_xyz[3 * p + 2] = x[2];
+    }
+    __syncthreads();
+    for (int p = tid; p < P; p += 256) {                                   // diff(projected; dims), :49-51
+        const int a = p % n1, b = p / n1;
+        const double *u = s_xyz + 3 * p;
+        if (a + 1 < n1) {
+            const double *w = u + 3;
+            const double d = sqrt((w[0] - u[0]) * (w[0] - u[0]) + (w[1] - u[1]) * (w[1] - u[1]) +
+                                  (w[2] - u[2]) * (w[2] - u[2])) - cs;
+            dist += d * d;
+        }
+        if (b + 1 < n2) {
+            const double *w = u + 3 * n1;
+            const double d = sqrt((w[0] - u[0]) * (w[0] - u[0]) + (w[1] - u[1]) * (w[1] - u[1]) +
+                                  (w[2] - u[2]) * (w[2] - u[2])) - cs;
+            dist += d * d;
+        }
+    }
+    if (inv_pts != nullptr) {
+        const double *pts = inv_pts + (size_t)2 * S * i;
+        for (int q = tid; q < S; q += 256) {                               // round trip, :53-58
+            const double m[2] = {pts[2 * q], pts[2 * q + 1]};
+            double x[3], rc[2];
+            map_inverse(m, f, c, k, R, ti, cs, x);
+            map_forward(x, f, c, k, R, t, 1.0 / cs, rc);
+            inv += (m[0] - rc[0]) * (m[0] - rc[0]) + (m[1] - rc[1]) * (m[1] - rc[1]);
+        }
+    }
+    s_acc[0][tid] = reproj; s_acc[1][tid] = proj; s_acc[2][tid] = dist; s_acc[3][tid] = inv;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {                                    // fixed-shape tree: deterministic
+        if (tid < w) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) s_acc[j][tid] += s_acc[j][tid + w];
+        }
+        __syncthreads();
+    }
+    if (tid < 4) partials[(size_t)4 * i + tid] = s_acc[tid][0];
+}
+
+// fixed-order sum of the per-image partials [4,N] -> out[4]
+__global__ __launch_bounds__(64) void k_errors_reduce(const double *__restrict__ partials, double *__restrict__ out,
+                                                      int N) {
+    const int j = threadIdx.x;
+    if (j >= 4) return;
+    double s = 0.0;
+    for (int i = 0; i < N; i++) s += partials[(size_t)4 * i + j];
+    out[j] = s;
+}
+
+hipError_t launch_map_forward(hipStream_t stream, const double *xyz, double *rc, int M, const double *par) {
+    hipLaunchKernelGGL(k_map_forward, dim3((M + 255) / 256), dim3(256), 0, stream, xyz, rc, M, par);
+    return hipGetLastError();
+}
+hipError_t launch_map_inverse(hipStream_t stream, const double *rc, double *xyz, int M, const double *par) {
+    hipLaunchKernelGGL(k_map_inverse, dim3((M + 255) / 256), dim3(256), 0, stream, rc, xyz, M, par);
+    return hipGetLastError();
+}
+hipError_t launch_errors(hipStream_t stream, const double *obj, const double *img, const double *par,
+                         const double *rt, const double *inv_pts, double *partials, int N, int n1, int n2, int S) {
+    const size_t lds = sizeof(double) * 3 * (size_t)n1 * n2;
+    hipLaunchKernelGGL(k_errors, dim3(N), dim3(256), lds, stream, obj, img, par, rt, inv_pts, partials, n1, n2, S);
+    hipLaunchKernelGGL(k_errors_reduce, dim3(1), dim3(64), 0, stream, partials, partials + (size_t)4 * N, N);
+    return hipGetLastError();
+}
+
+}  // namespace ccal

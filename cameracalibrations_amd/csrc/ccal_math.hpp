@@ -1,0 +1,269 @@
+// ccal_math.hpp -- per-lane / per-wave-uniform FP64 math of the camera-model fit.
+//
+// Everything here is plain inlined C++ over scalars and small fixed-size arrays with
+// compile-time indexing, so that on gfx950 the arrays live in VGPRs (never scratch).  The
+// functions are __host__ __device__ only so that tests/ can build a host shim of the SAME
+// math and compare it with the oracle on CPU; the product never runs them on the host.
+//
+// Model and Jacobians: OpenCV 5-coefficient projection as summarised in SURVEY.md A.2/A.3
+// (the arithmetic the reference reaches through src/detect_fit.jl:47); the Julia forward
+// model of src/meta.jl:39-44 is the k2 = k3 = p1 = p2 = 0 special case.
+#pragma once
+
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define CCAL_HD __host__ __device__ __forceinline__
+#else
+#define CCAL_HD inline
+#endif
+
+namespace ccal {
+
+constexpr int NINTR = 9;   // fx fy cx cy k1 k2 p1 p2 k3
+constexpr int NCOL = 16;   // Gram columns: 0-5 rvec,tvec | 6-14 intrinsic slots | 15 residual
+constexpr int COL_E = 15;
+
+// ---------------------------------------------------------------------------------------
+// Rodrigues vector -> rotation matrix (row-major) and d vec(R) / d r_j
+// ---------------------------------------------------------------------------------------
+CCAL_HD void rodrigues(const double r[3], double R[9], double dR[27]) {
+    const double th2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    const double th = sqrt(th2);
+    if (th < 2.220446049250313e-16) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 27; k++) dR[k] = 0.0;
+        dR[5] = dR[15] = dR[19] = -1.0;
+        dR[7] = dR[11] = dR[21] = 1.0;
+        return;
+    }
+    const double c = cos(th), s = sin(th), c1 = 1.0 - c, it = 1.0 / th;
+    const double n[3] = {r[0] * it, r[1] * it, r[2] * it};
+    double nn[9], nx[9] = {0.0, -n[2], n[1], n[2], 0.0, -n[0], -n[1], n[0], 0.0};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) nn[a * 3 + b] = n[a] * n[b];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * nn[k] + s * nx[k];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double dn[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) dn[a] = (((a == j) ? 1.0 : 0.0) - n[j] * n[a]) * it;
+        const double dnx[9] = {0.0, -dn[2], dn[1], dn[2], 0.0, -dn[0], -dn[1], dn[0], 0.0};
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                const int k = a * 3 + b;
+                dR[j * 9 + k] = n[j] * (-s * ((a == b) ? 1.0 : 0.0) + s * nn[k] + c * nx[k]) +
+                                c1 * (dn[a] * n[b] + n[a] * dn[b]) + s * dnx[k];
+            }
+    }
+}
+
+// Rotation only (error-only evaluations, maps).
+CCAL_HD void rodrigues_R(const double r[3], double R[9]) {
+    const double th = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (th < 2.220446049250313e-16) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        return;
+    }
+    const double c = cos(th), s = sin(th), c1 = 1.0 - c, it = 1.0 / th;
+    const double n[3] = {r[0] * it, r[1] * it, r[2] * it};
+    R[0] = c + c1 * n[0] * n[0];        R[1] = c1 * n[0] * n[1] - s * n[2]; R[2] = c1 * n[0] * n[2] + s * n[1];
+    R[3] = c1 * n[1] * n[0] + s * n[2]; R[4] = c + c1 * n[1] * n[1];        R[5] = c1 * n[1] * n[2] - s * n[0];
+    R[6] = c1 * n[2] * n[0] - s * n[1]; R[7] = c1 * n[2] * n[1] + s * n[0]; R[8] = c + c1 * n[2] * n[2];
+}
+
+// ---------------------------------------------------------------------------------------
+// One corner: the two rows (u, v) of [Je | Ji | e]  
+//   cols 0-2 d/drvec, 3-5 d/dtvec, 6 fx, 7 fy, 8 cx, 9 cy, 10 k1, 11 k2, 12 p1, 13 p2, 14 k3, 15 e
+//   aspect > 0  <=>  CALIB_FIX_ASPECT_RATIO: fx column zero, fy column = (aspect*xd, yd)
+// ---------------------------------------------------------------------------------------
+CCAL_HD void point_rows(const double M[3], double u_obs, double v_obs, const double R[9],
+                        const double dR[27], const double t[3], const double in[NINTR],
+                        double aspect, double mu[NCOL], double mv[NCOL]) {
+    const double fx = in[0], fy = in[1], cx = in[2], cy = in[3];
+    const double k1 = in[4], k2 = in[5], p1 = in[6], p2 = in[7], k3 = in[8];
+    const double X = R[0] * M[0] + R[1] * M[1] + R[2] * M[2] + t[0];
+    const double Y = R[3] * M[0] + R[4] * M[1] + R[5] * M[2] + t[1];
+    const double Z = R[6] * M[0] + R[7] * M[1] + R[8] * M[2] + t[2];
+    const double z = (Z != 0.0) ? 1.0 / Z : 1.0;
+    const double x = X * z, y = Y * z;
+    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    const double a1 = 2.0 * x * y, a2 = r2 + 2.0 * x * x, a3 = r2 + 2.0 * y * y;
+    const double cd = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
+    const double xd = x * cd + p1 * a1 + p2 * a2;
+    const double yd = y * cd + p1 * a3 + p2 * a1;
+    const double dcd_dr2 = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4;
+
+    mu[COL_E] = fx * xd + cx - u_obs;
+    mv[COL_E] = fy * yd + cy - v_obs;
+    if (aspect > 0.0) { mu[6] = 0.0; mu[7] = xd * aspect; }
+    else              { mu[6] = xd;  mu[7] = 0.0; }
+    mv[6] = 0.0; mv[7] = yd;
+    mu[8] = 1.0; mu[9] = 0.0; mv[8] = 0.0; mv[9] = 1.0;
+    mu[10] = fx * x * r2; mu[11] = fx * x * r4; mu[12] = fx * a1; mu[13] = fx * a2; mu[14] = fx * x * r6;
+    mv[10] = fy * y * r2; mv[11] = fy * y * r4; mv[12] = fy * a3; mv[13] = fy * a1; mv[14] = fy * y * r6;
+
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double dX, dY, dZ;
+        if (j < 3) {
+            const double *D = dR + 9 * j;
+            dX = D[0] * M[0] + D[1] * M[1] + D[2] * M[2];
+            dY = D[3] * M[0] + D[4] * M[1] + D[5] * M[2];
+            dZ = D[6] * M[0] + D[7] * M[1] + D[8] * M[2];
+        } else {
+            dX = (j == 3) ? 1.0 : 0.0; dY = (j == 4) ? 1.0 : 0.0; dZ = (j == 5) ? 1.0 : 0.0;
+        }
+        const double dx = z * (dX - x * dZ), dy = z * (dY - y * dZ);
+        const double dr2 = 2.0 * x * dx + 2.0 * y * dy;
+        const double dcd = dcd_dr2 * dr2;
+        const double da1 = 2.0 * (x * dy + y * dx);
+        mu[j] = fx * (cd * dx + x * dcd + p1 * da1 + p2 * (dr2 + 4.0 * x * dx));
+        mv[j] = fy * (cd * dy + y * dcd + p1 * (dr2 + 4.0 * y * dy) + p2 * da1);
+    }
+}
+
+// Residual only (maps / error metrics use the single-k Julia model separately).
+CCAL_HD void point_residual(const double M[3], double u_obs, double v_obs, const double R[9],
+                            const double t[3], const double in[NINTR], double &eu, double &ev) {
+    const double X = R[0] * M[0] + R[1] * M[1] + R[2] * M[2] + t[0];
+    const double Y = R[3] * M[0] + R[4] * M[1] + R[5] * M[2] + t[1];
+    const double Z = R[6] * M[0] + R[7] * M[1] + R[8] * M[2] + t[2];
+    const double z = (Z != 0.0) ? 1.0 / Z : 1.0;
+    const double x = X * z, y = Y * z;
+    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    const double a1 = 2.0 * x * y, a2 = r2 + 2.0 * x * x, a3 = r2 + 2.0 * y * y;
+    const double cd = 1.0 + in[4] * r2 + in[5] * r4 + in[8] * r6;
+    eu = in[0] * (x * cd + in[6] * a1 + in[7] * a2) + in[2] - u_obs;
+    ev = in[1] * (y * cd + in[6] * a3 + in[7] * a1) + in[3] - v_obs;
+}
+
+// ---------------------------------------------------------------------------------------
+// Small dense LA on fixed-size, fully unrolled arrays (wave-uniform values in VGPRs)
+// ---------------------------------------------------------------------------------------
+// packed lower-triangular index, a >= b
+CCAL_HD constexpr int tri(int a, int b) { return a * (a + 1) / 2 + b; }
+
+// In-place Cholesky of a packed lower SPD matrix: A = L L^T.  Returns false when a pivot
+// is not strictly positive (or NaN); the factor is then unusable.
+template <int N>
+CCAL_HD bool chol_packed(double A[N * (N + 1) / 2]) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        double d = A[tri(j, j)];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= A[tri(j, k)] * A[tri(j, k)];
+        ok = ok && (d > 0.0);
+        const double dj = sqrt(d);
+        const double inv = 1.0 / dj;
+        A[tri(j, j)] = dj;
+#pragma unroll
+        for (int i = j + 1; i < N; i++) {
+            double s = A[tri(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; k++) s -= A[tri(i, k)] * A[tri(j, k)];
+            A[tri(i, j)] = s * inv;
+        }
+    }
+    return ok;
+}
+
+// y = L^-1 b  (forward substitution), in place
+template <int N>
+CCAL_HD void fwd_subst(const double L[N * (N + 1) / 2], double b[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= L[tri(i, k)] * b[k];
+        b[i] = s / L[tri(i, i)];
+    }
+}
+// x = L^-T y  (back substitution), in place
+template <int N>
+CCAL_HD void bwd_subst(const double L[N * (N + 1) / 2], double b[N]) {
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+        double s = b[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++) s -= L[tri(k, i)] * b[k];
+        b[i] = s / L[tri(i, i)];
+    }
+}
+
+// Marquardt damping of a packed lower matrix: diag *= 1 + lambda (CvLevMarq::step, A.6)
+template <int N>
+CCAL_HD void damp_diag(double A[N * (N + 1) / 2], double lambda) {
+#pragma unroll
+    for (int j = 0; j < N; j++) A[tri(j, j)] *= 1.0 + lambda;
+}
+
+// ---------------------------------------------------------------------------------------
+// Julia-side maps (reference src/meta.jl), single radial coefficient k
+// ---------------------------------------------------------------------------------------
+// largest real root of c0 + x^2 - x^3 (src/meta.jl:50-57), closed form + Newton polish
+CCAL_HD double max_real_root_cubic(double c0) {
+    const double p = -1.0 / 3.0, q = -2.0 / 27.0 - c0;
+    const double disc = q * q * 0.25 + p * p * p / 27.0;
+    double x;
+    if (disc > 0.0) {
+        const double sq = sqrt(disc);
+        x = cbrt(-0.5 * q + sq) + cbrt(-0.5 * q - sq) + 1.0 / 3.0;
+    } else {
+        const double rho = 2.0 * sqrt(-p / 3.0);
+        double arg = 3.0 * q / (p * rho);
+        arg = arg > 1.0 ? 1.0 : (arg < -1.0 ? -1.0 : arg);
+        x = rho * cos(acos(arg) / 3.0) + 1.0 / 3.0;
+    }
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+        const double fx = ((x - 1.0) * x) * x - c0, dfx = (3.0 * x - 2.0) * x;
+        if (dfx != 0.0) x -= fx / dfx;
+    }
+    return x;
+}
+
+// real2image: intrinsic o distort o perspective o extrinsic o scale (src/meta.jl:27-33,39-44)
+CCAL_HD void map_forward(const double xyz[3], const double f[2], const double c[2], double k,
+                         const double R[9], const double t[3], double inv_cs, double rc[2]) {
+    const double s0 = xyz[0] * inv_cs, s1 = xyz[1] * inv_cs, s2 = xyz[2] * inv_cs;
+    const double X = R[0] * s0 + R[1] * s1 + R[2] * s2 + t[0];
+    const double Y = R[3] * s0 + R[4] * s1 + R[5] * s2 + t[1];
+    const double Z = R[6] * s0 + R[7] * s1 + R[8] * s2 + t[2];
+    double v0 = X / Z, v1 = Y / Z;
+    if (k != 0.0) {
+        const double radial = 1.0 + k * (v0 * v0 + v1 * v1);
+        v0 *= radial; v1 *= radial;
+    }
+    rc[0] = f[0] * v0 + c[0];
+    rc[1] = f[1] * v1 + c[1];
+}
+
+// image2real: inv_scale o inv_extrinsic o inv_perspective o inv_distort o inv_intrinsic
+// (src/meta.jl:50-76,82).  ti = -R^T t.
+CCAL_HD void map_inverse(const double rc[2], const double f[2], const double c[2], double k,
+                         const double R[9], const double ti[3], double cs, double xyz[3]) {
+    double v0 = (rc[0] - c[0]) / f[0], v1 = (rc[1] - c[1]) / f[1];
+    if (k != 0.0) {
+        const double rho = max_real_root_cubic(k * (v0 * v0 + v1 * v1));
+        v0 /= rho; v1 /= rho;
+    }
+    // depth(rc1, t, l) = -t / (l . rc1), l = last row of R^T (src/meta.jl:60-69)
+    const double d = -ti[2] / (R[2] * v0 + R[5] * v1 + R[8]);
+    const double p0 = d * v0, p1 = d * v1, p2 = d;
+    xyz[0] = cs * (R[0] * p0 + R[3] * p1 + R[6] * p2 + ti[0]);
+    xyz[1] = cs * (R[1] * p0 + R[4] * p1 + R[7] * p2 + ti[1]);
+    xyz[2] = cs * (R[2] * p0 + R[5] * p1 + R[8] * p2 + ti[2]);
+}
+
+}  // namespace ccal

@@ -1,0 +1,71 @@
+// ccal_state.hpp -- device-resident layouts shared by the kernels and the host driver.
+//
+// HBM layout of one fit (N = images on this GPU, P = corners per image):
+//   obj      [3,P]      f32   board template (shared by every image)
+//   img      [2,P,N]    f32   observed corners; the only O(N*P) stream: 8 B per corner-residual
+//   ext      [2][N][8]  f64   rvec,tvec (+2 pad) per image, double-buffered: parity p holds the
+//                             last ACCEPTED point ("prev"), 1-p the candidate being evaluated
+//   blk      [2][N][88] f64   per-image normal-equation blocks C (6x6 packed, 21) | B (9x6) | h (6),
+//                             same double-buffering; kept so that a rejected step can be
+//                             re-solved with a larger lambda without another sweep
+//   partials [nblk][112] f64  per-workgroup partial sums of the reduced intrinsic system
+//   red      [112]      f64   the reduced system (what is all-reduced across GPUs)
+//   LmState             the OpenCV CvLevMarq state machine, advanced on device
+#pragma once
+
+#include <stdint.h>
+
+namespace ccal {
+
+constexpr int NRED = 112;      // doubles in the reduced system
+constexpr int RED_A = 0;       // A  = sum Ji^T Ji          packed lower 9x9 (45)
+constexpr int RED_G = 45;      // g  = sum Ji^T e           (9)
+constexpr int RED_SC = 54;     // SC = sum B C_l^-1 B^T     packed lower 9x9 (45)
+constexpr int RED_SG = 99;     // sg = sum B C_l^-1 h       (9)
+constexpr int RED_ERR = 108;   // sum ||e||^2
+constexpr int RED_DNUM = 109;  // sum ||ext_cand - ext_prev||^2
+constexpr int RED_DDEN = 110;  // sum ||ext_prev||^2
+constexpr int RED_BAD = 111;   // images with a non-PD block or non-finite error
+
+constexpr int BLK = 88;        // per-image block stride (doubles)
+constexpr int BLK_C = 0;       // C packed lower 6x6
+constexpr int BLK_B = 21;      // B[a][k], a = intrinsic slot 0..8, k = extrinsic 0..5
+constexpr int BLK_H = 75;      // h[k]
+constexpr int BLK_USED = 81;
+constexpr int EXT = 8;         // per-image extrinsic stride (doubles)
+
+enum : int { MODE_INIT = 0, MODE_EVAL = 1, MODE_RESCHUR = 2 };
+constexpr int MAX_KINDS = 64;
+
+struct LmState {
+    int32_t mode;          // what the NEXT sweep does
+    int32_t done;
+    int32_t parity;        // ext/blk buffer holding the accepted point
+    int32_t lambda_lg10;   // OpenCV lambdaLg10
+    int32_t lg_partials;   // log10(lambda) the sweep must use for its Schur partials
+    int32_t iters;
+    int32_t max_iter;
+    int32_t sweeps, reschur, rejected, trials;
+    int32_t n_trace, max_trace;
+    int32_t n_bad;
+    int32_t status;        // 0 ok, CCAL_E_NONFINITE ...
+    int32_t P, N_local, nblocks;
+    int64_t N_global;
+    double eps;
+    double aspect;         // > 0 <=> CALIB_FIX_ASPECT_RATIO
+    double lam_step;       // lambda of the step being evaluated (back-substitution)
+    double lam_next;       // lambda for the Schur partials of this sweep
+    double prev_err, rel_step;
+    double intr_prev[9], intr_cand[9], dint[9];
+    int32_t mask[9];
+    int32_t pad_;
+    double A_prev[45], g_prev[9];
+    int32_t kinds[MAX_KINDS];   // per trial: 1 + mode of the sweep it ran (0 = no-op after `done`)
+};
+
+struct TraceRec {          // mirrors ccal_trace in include/ccal.h
+    double err, rel_step;
+    int32_t accepted, lambda_lg10, iters, pad;
+};
+
+}  // namespace ccal

@@ -1,0 +1,214 @@
+"""Host-side handle on the device fit (thin wrapper over the C ABI, include/ccal.h).
+
+`Solver` exposes the stages of OpenCV's calibrateCamera that the reference reaches through
+its single FFI call (reference src/detect_fit.jl:47) so that tests can compare each stage
+with the oracle; `fit_model` below mirrors the reference's own wrapper function
+(src/detect_fit.jl:27-61): same arguments, same NamedTuple-like result.
+"""
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import _ffi as F
+
+
+class Solver:
+    """One device context (`ccal_ctx`).  Not thread-safe; use one per host thread."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        F.check(F.lib().ccal_create(int(device), C.byref(self._h)))
+        self._keep = []          # arrays / callbacks that must outlive the device work
+        self.N = self.P = 0
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if self._h:
+            F.lib().ccal_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- configuration ------------------------------------------------------------------
+    def set_stream(self, stream):
+        """stream: a hipStream_t handle as int (e.g. torch.cuda.current_stream().cuda_stream)."""
+        F.check(F.lib().ccal_set_stream(self._h, C.c_void_p(int(stream) if stream else None)))
+
+    def set_allreduce(self, fn, world_size, rank, n_images_global):
+        """fn(device_ptr:int, n:int, stream:int) -> 0 sums n doubles in place across ranks."""
+        def _tramp(_user, buf, n, stream):
+            try:
+                return int(fn(int(buf or 0), int(n), int(stream or 0)) or 0)
+            except Exception:  # never unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return -1
+        cb = F.ALLREDUCE_FN(_tramp)
+        self._keep.append(cb)
+        F.check(F.lib().ccal_set_allreduce(self._h, cb, None, int(world_size), int(rank), int(n_images_global)))
+
+    def set_problem(self, obj, n_images, image_size, aspect=1.0, flags=0, max_iter=30, eps=1e-3):
+        """obj (P,3); image_size = (width, height) as OpenCV sees it (src/detect_fit.jl:32)."""
+        obj, op = F.f32(obj)
+        assert obj.ndim == 2 and obj.shape[1] == 3
+        self.P, self.N = obj.shape[0], int(n_images)
+        F.check(F.lib().ccal_set_problem(self._h, op, self.P, self.N, int(image_size[0]), int(image_size[1]),
+                                         float(aspect), int(flags), int(max_iter), float(eps)))
+
+    def set_image_points(self, img):
+        """img (N,P,2) float32 host array (copied), or a torch CUDA tensor (used in place)."""
+        if hasattr(img, "data_ptr") and getattr(img, "is_cuda", False):
+            assert tuple(img.shape) == (self.N, self.P, 2) and img.is_contiguous() and str(img.dtype) == "torch.float32"
+            self._keep.append(img)
+            F.check(F.lib().ccal_set_image_points_device(self._h, C.c_void_p(img.data_ptr())))
+            return
+        img, ip = F.f32(img)
+        assert img.shape == (self.N, self.P, 2), (img.shape, (self.N, self.P, 2))
+        F.check(F.lib().ccal_set_image_points(self._h, ip))
+
+    # -- stages -------------------------------------------------------------------------
+    def init_intrinsics(self):
+        F.check(F.lib().ccal_init_intrinsics(self._h))
+
+    def set_intrinsics(self, intr):
+        F.check(F.lib().ccal_set_intrinsics(self._h, F.f64(intr)[1]))
+
+    def init_extrinsics(self):
+        F.check(F.lib().ccal_init_extrinsics(self._h))
+
+    def set_extrinsics(self, rt):
+        rt, rp = F.f64(rt)
+        assert rt.shape == (self.N, 6)
+        F.check(F.lib().ccal_set_extrinsics(self._h, rp))
+
+    def get_init(self, extrinsics=True):
+        intr, ip = F.out64(F.NINTR)
+        rt, rp = F.out64(self.N, 6)
+        F.check(F.lib().ccal_get_init(self._h, ip, rp if extrinsics else None))
+        return intr, (rt if extrinsics else None)
+
+    def set_sweep_timing(self, enable=True):
+        F.check(F.lib().ccal_set_sweep_timing(self._h, int(bool(enable))))
+
+    def lm_run(self):
+        return F.check(F.lib().ccal_lm_run(self._h))
+
+    def result(self):
+        intr, ip = F.out64(F.NINTR)
+        rv, rvp = F.out64(self.N, 3)
+        tv, tvp = F.out64(self.N, 3)
+        st = F.Stats()
+        F.check(F.lib().ccal_get_result(self._h, ip, rvp, tvp, C.byref(st)))
+        return dict(intr=intr, K4=intr[:4].copy(), dist5=intr[4:].copy(), rvecs=rv, tvecs=tv, **st.asdict())
+
+    def trace(self, max_entries=4096):
+        buf = (F.Trace * max_entries)()
+        n = C.c_int32(0)
+        F.check(F.lib().ccal_get_trace(self._h, buf, max_entries, C.byref(n)))
+        return [dict(err=t.err, rel_step=t.rel_step, accepted=t.accepted, lambda_lg10=t.lambda_lg10, iters=t.iters)
+                for t in buf[: n.value]]
+
+    def calibrate(self, init_intr=None, init_rt=None):
+        """init (device) -> LM (device) -> result dict; returns (status, result)."""
+        if init_intr is not None:
+            self.set_intrinsics(init_intr)
+        else:
+            self.init_intrinsics()
+        if init_rt is not None:
+            self.set_extrinsics(init_rt)
+        else:
+            self.init_extrinsics()
+        status = self.lm_run()
+        return status, self.result()
+
+    # -- maps / metrics -----------------------------------------------------------------
+    def project(self, xyz, f, c, k, rvec, tvec, checker_size=1.0):
+        xyz, xp = F.f64(np.atleast_2d(xyz))
+        out, o = F.out64(xyz.shape[0], 2)
+        F.check(F.lib().ccal_project(self._h, xp, xyz.shape[0], F.f64(f)[1], F.f64(c)[1], float(k), F.f64(rvec)[1],
+                                     F.f64(tvec)[1], float(checker_size), o))
+        return out
+
+    def unproject(self, rc, f, c, k, rvec, tvec, checker_size=1.0):
+        rc, rp = F.f64(np.atleast_2d(rc))
+        out, o = F.out64(rc.shape[0], 3)
+        F.check(F.lib().ccal_unproject(self._h, rp, rc.shape[0], F.f64(f)[1], F.f64(c)[1], float(k), F.f64(rvec)[1],
+                                       F.f64(tvec)[1], float(checker_size), o))
+        return out
+
+    def errors(self, n_corners, obj_scaled, img, f, c, k, rvecs, tvecs, checker_size, inv_pts=None):
+        obj, op = F.f64(obj_scaled)
+        img, ip = F.f64(img)
+        N = img.shape[0]
+        S, pp = 0, None
+        if inv_pts is not None:
+            pts, pp = F.f64(inv_pts)
+            S = pts.shape[1]
+        out, o = F.out64(4)
+        F.check(F.lib().ccal_errors(self._h, N, int(n_corners[0]), int(n_corners[1]), op, ip, F.f64(f)[1], F.f64(c)[1],
+                                    float(k), F.f64(rvecs)[1], F.f64(tvecs)[1], float(checker_size), S, pp, o))
+        return dict(reprojection=out[0], projection=out[1], distance=out[2], inverse=out[3])
+
+    # -- diagnostics --------------------------------------------------------------------
+    def image_grams(self, intr, rt):
+        rt, rp = F.f64(rt)
+        G, gp = F.out64(self.N, 16, 16)
+        F.check(F.lib().ccal_debug_image_grams(self._h, F.f64(intr)[1], rp, gp))
+        return G
+
+    def time_sweep(self, reps=50):
+        v = C.c_double(0)
+        F.check(F.lib().ccal_time_sweep(self._h, int(reps), C.byref(v)))
+        return v.value
+
+
+def device_count():
+    return F.lib().ccal_device_count()
+
+
+# reference flag word, src/detect_fit.jl:40
+def reference_flags(with_distortion=True):
+    return (F.ZERO_TANGENT_DIST | F.FIX_K3 | F.FIX_K2 | (0 if with_distortion else F.FIX_K1) | F.FIX_ASPECT_RATIO)
+
+
+CRITERIA = (30, 0.001)   # TermCriteria(EPS + MAX_ITER, 30, 0.001), src/CameraCalibrations.jl:16
+
+
+def fit_model(sz, objpoints, imgpointss, n_corners, with_distortion, aspect, device=0):
+    """Drop-in for the reference's `fit_model` (src/detect_fit.jl:27-61).
+
+    sz = size of the Julia image (rows, cols) == OpenCV (width, height); objpoints = the
+    n1 x n2 x 1 template of XYZ (any array reshaping to (P,3), first dim fastest);
+    imgpointss = list of per-image corner arrays (each reshaping to (P,2));
+    returns a namespace (k, Rs, ts, frow, fcol, crow, ccol) like the NamedTuple at :60.
+    """
+    P = int(n_corners[0]) * int(n_corners[1])
+    obj = np.asarray(objpoints, dtype=np.float32).reshape(P, 3)
+    img = np.stack([np.asarray(m, dtype=np.float32).reshape(P, 2) for m in imgpointss])
+    K4 = np.zeros(4)
+    dist5 = np.zeros(5)
+    N = img.shape[0]
+    rv, tv = np.zeros((N, 3)), np.zeros((N, 3))
+    rms, iters = C.c_double(0), C.c_int32(0)
+    st = F.Stats()
+    op, ip = F.f32(obj)[1], F.f32(img)[1]
+    dp = F._dp
+    F.check(F.lib().ccal_calibrate(op, ip, P, N, int(sz[0]), int(sz[1]), float(aspect),
+                                   reference_flags(with_distortion), CRITERIA[0], CRITERIA[1], int(device),
+                                   K4.ctypes.data_as(dp), dist5.ctypes.data_as(dp), rv.ctypes.data_as(dp),
+                                   tv.ctypes.data_as(dp), C.byref(rms), C.byref(iters), C.byref(st)))
+    return SimpleNamespace(k=float(dist5[0]), Rs=[r.copy() for r in rv], ts=[t.copy() for t in tv],
+                           frow=float(K4[0]), fcol=float(K4[1]), crow=float(K4[2]), ccol=float(K4[3]),
+                           rms=rms.value, iters=iters.value, stats=st.asdict())

@@ -1,0 +1,180 @@
+/*
+ * ccal.h -- C ABI of the MI355X-native camera-model fit (libccal_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of yakir12/CameraCalibrations:
+ * the Julia function `fit_model` (reference src/detect_fit.jl:27-61), whose body is a
+ * single CxxWrap call into OpenCV 4.10 `calibrateCamera` (src/detect_fit.jl:47), plus the
+ * RowCol <-> XYZ point maps and error metrics that consume its result
+ * (src/meta.jl:27-103, src/buildcalibrations.jl:1-67).  Each entry point below names the
+ * reference interface it replaces.  Julia binds these with `ccall`, the tests with
+ * Python `ctypes` (INTEGRATION.md shows both stubs).
+ *
+ * Conventions
+ *   - plain C types only; every array is caller-owned, contiguous, Julia column-major:
+ *       obj  [3,P]   Float32   board template, first n_corners dim fastest, z = 0
+ *                              (src/detect_fit.jl:69, marshalled at :30)
+ *       img  [2,P,N] Float32   observed corners, RowCol = (x_cv, y_cv) (src/detect_fit.jl:31)
+ *       rvecs/tvecs [3,N] Float64 (src/detect_fit.jl:51-52)
+ *   - every function returns an int status: 0 ok, > 0 warning, < 0 error; no exception
+ *     ever crosses the boundary (the reference surfaces cv::Exception through CxxWrap).
+ *     `ccal_last_error()` gives the thread-local message of the last failure.
+ *   - a context is used by one host thread at a time; different contexts are independent
+ *     (the reference's FFI wrapper is exercised under Threads.@threads, test/runtests.jl:45-51).
+ *   - all arithmetic is FP64 on the device; there is NO CPU fallback: without a usable
+ *     gfx950 device every compute entry point fails with CCAL_E_DEVICE.
+ */
+#ifndef CCAL_H
+#define CCAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCAL_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define CCAL_OK            0
+#define CCAL_W_MAX_ITER    1   /* stopped on max_iter, not on eps */
+#define CCAL_E_ARG        -1   /* bad argument / unsupported flag (rational, thin-prism, tilted models) */
+#define CCAL_E_NONPLANAR  -2   /* template not planar with z == 0 and no intrinsic guess (OpenCV throws likewise) */
+#define CCAL_E_DEGENERATE -3   /* homography / pose initialisation failed */
+#define CCAL_E_NONFINITE  -4   /* non-finite residual or parameter on the device */
+#define CCAL_E_DEVICE     -5   /* HIP error, no gfx950 device, out of memory */
+#define CCAL_E_COMM       -6   /* the all-reduce hook failed */
+#define CCAL_E_STATE      -7   /* call order violated (e.g. LM before initialisation) */
+
+/* OpenCV calib3d flag word, same bit values as the reference builds at src/detect_fit.jl:40 */
+#define CCAL_USE_INTRINSIC_GUESS 0x00001
+#define CCAL_FIX_ASPECT_RATIO    0x00002
+#define CCAL_FIX_PRINCIPAL_POINT 0x00004
+#define CCAL_ZERO_TANGENT_DIST   0x00008
+#define CCAL_FIX_FOCAL_LENGTH    0x00010
+#define CCAL_FIX_K1              0x00020
+#define CCAL_FIX_K2              0x00040
+#define CCAL_FIX_K3              0x00080
+#define CCAL_FIX_TANGENT_DIST    0x200000
+
+#define CCAL_NINTR 9   /* fx fy cx cy k1 k2 p1 p2 k3 */
+
+typedef struct ccal_ctx ccal_ctx;
+
+/* Per-fit statistics (the reference returns only the parameters; OpenCV's rms is discarded
+ * at src/detect_fit.jl:47).  Times are host wall-clock around device work, seconds. */
+typedef struct ccal_stats {
+    double rms;            /* sqrt(sum ||e||^2 / (N_global * P)) at the returned point */
+    double final_err;      /* sum ||e||^2 */
+    double rel_step;       /* last ||p - prev|| / ||prev|| */
+    double t_init_intr_s;  /* A4: homographies + focal least squares */
+    double t_init_extr_s;  /* A5: per-view pose initialisation */
+    double t_lm_s;         /* A6-A9: global LM loop */
+    int32_t iters;         /* accepted LM iterations (OpenCV `iters`) */
+    int32_t sweeps;        /* residual+Jacobian sweeps over all corners */
+    int32_t reschur;       /* extra damping-only passes after rejected steps */
+    int32_t rejected;      /* rejected trial steps */
+    int32_t lambda_lg10;   /* final log10(lambda) */
+    int32_t n_bad;         /* images whose 6x6 block was not positive definite in the last sweep */
+    int32_t timed_sweeps;  /* sweeps covered by sweep_us (0 unless ccal_set_sweep_timing is on) */
+    int32_t pad_;
+    double sweep_us;       /* mean device time of the sweep kernel, HIP events on the launch stream */
+} ccal_stats;
+
+/* One LM decision, for trajectory parity tests against the oracle. */
+typedef struct ccal_trace {
+    double err;            /* sum ||e||^2 at the evaluated candidate */
+    double rel_step;       /* when accepted, else -1 */
+    int32_t accepted;      /* 1 accepted, 0 rejected, 2 initial evaluation */
+    int32_t lambda_lg10;   /* after the decision */
+    int32_t iters;         /* after the decision */
+    int32_t pad;
+} ccal_trace;
+
+int         ccal_version(void);
+const char *ccal_last_error(void);
+/* number of usable gfx950 devices (0 if none); never fails */
+int         ccal_device_count(void);
+
+/* ---- context ------------------------------------------------------------------------ */
+int  ccal_create(int device, ccal_ctx **out);
+void ccal_destroy(ccal_ctx *ctx);
+/* run all device work on the caller's hipStream_t (e.g. PyTorch's current stream);
+ * NULL restores the context's own stream. */
+int  ccal_set_stream(ccal_ctx *ctx, void *hip_stream);
+
+/* Multi-GPU: images are sharded one-extrinsic-block-per-GPU.  The hook must
+ * sum `n` doubles in place across ranks on `hip_stream` (RCCL all-reduce).  world_size == 1
+ * or fn == NULL disables it.  n_images_global = total images over all ranks. */
+typedef int (*ccal_allreduce_fn)(void *user, void *device_buf, int32_t n, void *hip_stream);
+int  ccal_set_allreduce(ccal_ctx *ctx, ccal_allreduce_fn fn, void *user, int32_t world_size,
+                        int32_t rank, int64_t n_images_global);
+
+/* ---- problem ------------------------------------------------------------------------ */
+/* Replaces the marshalling of fit_model (src/detect_fit.jl:30-45): template, image size
+ * (width, height) as OpenCV sees it == Julia size(img) (src/detect_fit.jl:32), aspect
+ * (cameraMatrix(0,0)/cameraMatrix(1,1), src/detect_fit.jl:34-36), flag word (:40) and
+ * TermCriteria (src/CameraCalibrations.jl:16).  `obj` is a host pointer. */
+int  ccal_set_problem(ccal_ctx *ctx, const float *obj, int32_t P, int32_t N, int32_t width,
+                      int32_t height, double aspect, uint32_t flags, int32_t max_iter, double eps);
+/* observed corners [2,P,N]: host copy (drop-in path) or a device pointer that already
+ * lives in HBM (bench / torch tensors); the device pointer must stay valid until replaced. */
+int  ccal_set_image_points(ccal_ctx *ctx, const float *img_host);
+int  ccal_set_image_points_device(ccal_ctx *ctx, const float *img_device);
+
+/* ---- stages of calibrateCamera (src/detect_fit.jl:47) -------------------------------- */
+/* A4 initial intrinsics from per-image homographies; or supply them (USE_INTRINSIC_GUESS). */
+int  ccal_init_intrinsics(ccal_ctx *ctx);
+int  ccal_set_intrinsics(ccal_ctx *ctx, const double intr[CCAL_NINTR]);
+/* A5 per-view pose initialisation; or supply [6,N] = rvec,tvec per image. */
+int  ccal_init_extrinsics(ccal_ctx *ctx);
+int  ccal_set_extrinsics(ccal_ctx *ctx, const double *rt_host);
+/* A6-A9 global Levenberg-Marquardt with OpenCV's schedule, on the device. */
+int  ccal_lm_run(ccal_ctx *ctx);
+/* Bracket every sweep launch of the next ccal_lm_run calls with a HIP event pair on the launch
+ * stream and report the mean in ccal_stats.sweep_us (roofline figure of bench.py). */
+int  ccal_set_sweep_timing(ccal_ctx *ctx, int32_t enable);
+/* results (any pointer may be NULL) */
+int  ccal_get_result(ccal_ctx *ctx, double intr[CCAL_NINTR], double *rvecs, double *tvecs,
+                     ccal_stats *stats);
+int  ccal_get_trace(ccal_ctx *ctx, ccal_trace *out, int32_t max_entries, int32_t *n_entries);
+
+/* ---- one-shot drop-in for fit_model / OpenCV.calibrateCamera ------------------------- */
+/* Replaces src/detect_fit.jl:47 including its un-marshalling (:49-60): K4 = fx fy cx cy
+ * (frow fcol crow ccol), dist5 = k1 k2 p1 p2 k3 (`k = first(dist)`), rvecs/tvecs [3,N]. */
+int  ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int32_t width,
+                    int32_t height, double aspect, uint32_t flags, int32_t max_iter, double eps,
+                    int32_t device, double K4[4], double dist5[5], double *rvecs, double *tvecs,
+                    double *rms, int32_t *iters, ccal_stats *stats);
+
+/* ---- point maps and error metrics (src/meta.jl, src/buildcalibrations.jl) ------------ */
+/* real2image[i] (src/meta.jl:27-33,39-44,88): xyz [3,M] -> rowcol [2,M], host arrays. */
+int  ccal_project(ccal_ctx *ctx, const double *xyz, int32_t M, const double f[2], const double c[2],
+                  double k, const double rvec[3], const double tvec[3], double checker_size,
+                  double *rowcol);
+/* image2real[i] (src/meta.jl:50-76,82): rowcol [2,M] -> xyz [3,M] on the board plane. */
+int  ccal_unproject(ccal_ctx *ctx, const double *rowcol, int32_t M, const double f[2],
+                    const double c[2], double k, const double rvec[3], const double tvec[3],
+                    double checker_size, double *xyz);
+/* calculate_errors (src/buildcalibrations.jl:37-67): out = reprojection, projection,
+ * distance, inverse.  obj_scaled [3,P] Float64 (template * checker_size), img [2,P,N] Float64,
+ * inv_pts [2,S,N] caller-supplied round-trip samples (the reference uses the global RNG). */
+int  ccal_errors(ccal_ctx *ctx, int32_t N, int32_t n1, int32_t n2, const double *obj_scaled,
+                 const double *img, const double f[2], const double c[2], double k,
+                 const double *rvecs, const double *tvecs, double checker_size, int32_t S,
+                 const double *inv_pts, double out[4]);
+
+/* ---- diagnostics (stage-wise parity tests; not part of the reference surface) -------- */
+/* per-image 16x16 Gram matrices [Je|Ji|e]^T[Je|Ji|e] at the given point -> G [256,N] host */
+int  ccal_debug_image_grams(ccal_ctx *ctx, const double intr[CCAL_NINTR], const double *rt_host,
+                            double *G_host);
+/* current initial values held by the context: intr[9], rt [6,N] */
+int  ccal_get_init(ccal_ctx *ctx, double intr[CCAL_NINTR], double *rt_host);
+/* average device time (microseconds, HIP events on the context's stream) of `reps` launches
+ * of the residual+Jacobian sweep kernel at the current point; used by bench.py for the
+ * roofline figure.  Does not change the LM state. */
+int  ccal_time_sweep(ccal_ctx *ctx, int32_t reps, double *avg_us);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCAL_H */

@@ -1,0 +1,56 @@
+"""CPU tests of the boundary: libccal_hip.so builds (hipcc cross-compiles gfx950 without a
+GPU), loads, exports every symbol include/ccal.h declares, and fails loudly without a device.
+No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from cameracalibrations_amd import _ffi as F
+from cameracalibrations_amd import build as B
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    B.build()
+    return F.lib()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "ccal.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ccal_[a-z_0-9]+)\s*\(", hdr)) - {"ccal_allreduce_fn"}
+    assert declared == set(F.SIGNATURES), declared ^ set(F.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ccal_version() == 100
+
+
+def test_no_cpu_fallback(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert lib.ccal_device_count() == 0
+    h = C.c_void_p()
+    assert lib.ccal_create(0, C.byref(h)) == F.E_DEVICE
+    assert b"no CPU fallback" in lib.ccal_last_error()
+    from cameracalibrations_amd.solver import Solver
+    with pytest.raises(F.CcalError):
+        Solver(0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "cameracalibrations_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and "from oracle" not in text and "ccal_oracle" not in text, f
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(F.Trace) == 32
+    assert C.sizeof(F.Stats) == 6 * 8 + 8 * 4 + 8
