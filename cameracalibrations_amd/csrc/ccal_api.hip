@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -53,6 +54,7 @@ struct ccal_ctx {
     double *d_ext = nullptr, *d_ext0 = nullptr, *d_blk = nullptr, *d_partials = nullptr, *d_red = nullptr;
     double *d_H = nullptr, *d_foc_partials = nullptr, *d_foc_red = nullptr, *d_gram = nullptr;
     int *d_fail = nullptr;
+    double *d_intr0 = nullptr, *d_intr_scratch = nullptr;   // initial intrinsics [9] on the device
     LmState *d_st = nullptr, *d_st_scratch = nullptr;
     TraceRec *d_trace = nullptr;
     int max_trace = 4096;
@@ -68,11 +70,14 @@ struct ccal_ctx {
     void *ar_user = nullptr;
     int world = 1, rank = 0;
     int64_t n_global = 0;
-    int lm_batch = 4;
+    int lm_batch = 8;
     // optional per-sweep event timing
     bool time_sweeps = false;
     std::vector<hipEvent_t> ev;   // 2 * MAX_KINDS events, created on demand
     int ev_used = 0;
+    // one solve = one replayable graph: begin + lm_batch x (sweep, solve) + state read-back
+    hipGraphExec_t g_first = nullptr, g_cont = nullptr;
+    bool graph_dirty = true, use_graph = true;
 };
 
 static void free_problem_buffers(ccal_ctx *c) {
@@ -121,11 +126,15 @@ int ccal_create(int device, ccal_ctx **out) {
     HIPCHK(hipMalloc(&c->d_red, sizeof(double) * NRED));
     HIPCHK(hipMalloc(&c->d_foc_red, sizeof(double) * NFOC));
     HIPCHK(hipMalloc(&c->d_fail, sizeof(int) * 4));
+    HIPCHK(hipMalloc(&c->d_intr0, sizeof(double) * 9));
+    HIPCHK(hipMalloc(&c->d_intr_scratch, sizeof(double) * 9));
     HIPCHK(hipMalloc(&c->d_trace, sizeof(TraceRec) * c->max_trace));
     HIPCHK(hipHostMalloc(&c->h_st, sizeof(LmState), hipHostMallocDefault));
     HIPCHK(hipHostMalloc(&c->h_flags, sizeof(int) * 16, hipHostMallocDefault));
     const char *b = getenv("CCAL_LM_BATCH");
     if (b && atoi(b) > 0) c->lm_batch = atoi(b);
+    const char *g = getenv("CCAL_NO_GRAPH");
+    if (g && atoi(g) != 0) c->use_graph = false;
     *out = c;
     return CCAL_OK;
 }
@@ -136,7 +145,9 @@ void ccal_destroy(ccal_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     free_problem_buffers(c);
     (void)hipFree(c->d_st); (void)hipFree(c->d_st_scratch); (void)hipFree(c->d_red); (void)hipFree(c->d_foc_red); (void)hipFree(c->d_fail);
-    (void)hipFree(c->d_trace);
+    (void)hipFree(c->d_trace); (void)hipFree(c->d_intr0); (void)hipFree(c->d_intr_scratch);
+    if (c->g_first) (void)hipGraphExecDestroy(c->g_first);
+    if (c->g_cont) (void)hipGraphExecDestroy(c->g_cont);
     (void)hipHostFree(c->h_st); (void)hipHostFree(c->h_flags);
     for (auto &e : c->ev) (void)hipEventDestroy(e);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -154,6 +165,7 @@ int ccal_set_allreduce(ccal_ctx *c, ccal_allreduce_fn fn, void *user, int32_t wo
     if (!c) return fail(CCAL_E_ARG, "ccal_set_allreduce: ctx == NULL");
     if (world_size < 1 || rank < 0 || rank >= world_size) return fail(CCAL_E_ARG, "ccal_set_allreduce: bad rank/world");
     if (world_size > 1 && (!fn || n_images_global < 1)) return fail(CCAL_E_ARG, "ccal_set_allreduce: hook missing");
+    c->graph_dirty = true;
     c->ar_fn = world_size > 1 ? fn : nullptr;
     c->ar_user = user;
     c->world = world_size;
@@ -200,6 +212,7 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
     c->P = P; c->N = N; c->width = width; c->height = height; c->aspect = aspect; c->flags = flags;
     c->max_iter = max_iter; c->eps = eps;
     c->have_problem = true;
+    c->graph_dirty = true;
     c->have_img = c->have_intr = c->have_ext = c->have_result = false;
     c->d_img = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
@@ -220,6 +233,7 @@ int ccal_set_image_points(ccal_ctx *c, const float *img_host) {
     }
     HIPCHK(hipMemcpyAsync(c->d_img_own, img_host, need, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->graph_dirty = c->graph_dirty || c->d_img != c->d_img_own;
     c->d_img = c->d_img_own;
     c->have_img = true;
     c->have_result = false;
@@ -234,6 +248,7 @@ int ccal_set_image_points_device(ccal_ctx *c, const float *img_device) {
         (void)hipGetLastError();
         return fail(CCAL_E_ARG, "ccal_set_image_points_device: not a device pointer");
     }
+    c->graph_dirty = c->graph_dirty || c->d_img != img_device;
     c->d_img = img_device;
     c->have_img = true;
     c->have_result = false;
@@ -247,6 +262,9 @@ int ccal_set_intrinsics(ccal_ctx *c, const double intr[CCAL_NINTR]) {
         if (!std::isfinite(intr[a])) return fail(CCAL_E_ARG, "ccal_set_intrinsics: non-finite value");
     if (!(intr[0] > 0 && intr[1] > 0)) return fail(CCAL_E_ARG, "ccal_set_intrinsics: focal lengths must be > 0");
     memcpy(c->intr0, intr, sizeof c->intr0);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->d_intr0, c->intr0, sizeof c->intr0, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     c->have_intr = true;
     c->have_result = false;
     return CCAL_OK;
@@ -274,33 +292,30 @@ static int run_allreduce(ccal_ctx *c, double *buf, int n) {
     return CCAL_OK;
 }
 
-static void host_state_defaults(ccal_ctx *c, LmState &s) {
-    memset(&s, 0, sizeof s);
-    s.mode = MODE_INIT;
-    s.lambda_lg10 = -3;
-    s.lg_partials = -3;
-    s.lam_next = std::exp(-3.0 * std::log(10.0));
-    s.lam_step = s.lam_next;
-    s.max_iter = c->max_iter;
-    s.eps = c->eps;
-    s.max_trace = c->max_trace;
-    s.P = c->P;
-    s.N_local = c->N;
-    s.nblocks = lm_sweep_blocks(c->N);
-    s.N_global = c->world > 1 ? c->n_global : c->N;
+static LmInit make_init(const ccal_ctx *c) {
+    LmInit in;
+    memset(&in, 0, sizeof in);
+    in.max_iter = c->max_iter;
+    in.eps = c->eps;
+    in.max_trace = c->max_trace;
+    in.P = c->P;
+    in.N_local = c->N;
+    in.nblocks = lm_sweep_blocks(c->N);
+    in.N_global = c->world > 1 ? c->n_global : c->N;
     // parameter mask from the flag word
     const uint32_t f = c->flags;
-    for (int a = 0; a < 9; a++) s.mask[a] = 1;
-    if (f & CCAL_FIX_ASPECT_RATIO) s.mask[0] = 0;
-    if (f & CCAL_FIX_FOCAL_LENGTH) s.mask[0] = s.mask[1] = 0;
-    if (f & CCAL_FIX_PRINCIPAL_POINT) s.mask[2] = s.mask[3] = 0;
-    if (f & (CCAL_ZERO_TANGENT_DIST | CCAL_FIX_TANGENT_DIST)) s.mask[6] = s.mask[7] = 0;
-    if (f & CCAL_FIX_K1) s.mask[4] = 0;
-    if (f & CCAL_FIX_K2) s.mask[5] = 0;
-    if (f & CCAL_FIX_K3) s.mask[8] = 0;
-    s.aspect = 0.0;
-    if (f & CCAL_FIX_ASPECT_RATIO)
-        s.aspect = (f & CCAL_USE_INTRINSIC_GUESS) ? c->intr0[0] / c->intr0[1] : c->aspect;
+    for (int a = 0; a < 9; a++) in.mask[a] = 1;
+    if (f & CCAL_FIX_ASPECT_RATIO) in.mask[0] = 0;
+    if (f & CCAL_FIX_FOCAL_LENGTH) in.mask[0] = in.mask[1] = 0;
+    if (f & CCAL_FIX_PRINCIPAL_POINT) in.mask[2] = in.mask[3] = 0;
+    if (f & (CCAL_ZERO_TANGENT_DIST | CCAL_FIX_TANGENT_DIST)) in.mask[6] = in.mask[7] = 0;
+    if (f & CCAL_FIX_K1) in.mask[4] = 0;
+    if (f & CCAL_FIX_K2) in.mask[5] = 0;
+    if (f & CCAL_FIX_K3) in.mask[8] = 0;
+    in.zero_tangent = (f & CCAL_ZERO_TANGENT_DIST) ? 1 : 0;
+    in.aspect = (f & CCAL_FIX_ASPECT_RATIO) ? c->aspect : 0.0;
+    in.aspect_from_guess = ((f & CCAL_FIX_ASPECT_RATIO) && (f & CCAL_USE_INTRINSIC_GUESS)) ? 1 : 0;
+    return in;
 }
 
 int ccal_init_intrinsics(ccal_ctx *c) {
@@ -310,20 +325,19 @@ int ccal_init_intrinsics(ccal_ctx *c) {
         return fail(CCAL_E_NONPLANAR, "For non-planar calibration rigs the initial intrinsic matrix must be specified");
     HIPCHK(hipSetDevice(c->device));
     const double t0 = now_s();
-    LmState &s = *c->h_st;
-    host_state_defaults(c, s);
-    HIPCHK(hipMemcpyAsync(c->d_st, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
     HIPCHK(launch_init_homography(c->stream, c->d_obj, c->d_img, c->d_H, c->d_foc_partials, c->N, c->P, c->width,
                                   c->height));
     HIPCHK(launch_init_focal_reduce(c->stream, c->d_foc_partials, c->d_foc_red, c->N));
     int rc = run_allreduce(c, c->d_foc_red, NFOC);
     if (rc) return rc;
     const double aspect = (c->flags & CCAL_FIX_ASPECT_RATIO) ? c->aspect : 0.0;
-    HIPCHK(launch_init_focal_solve(c->stream, c->d_foc_red, c->d_st, c->width, c->height, aspect));
-    HIPCHK(hipMemcpyAsync(c->h_st, c->d_st, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(launch_init_focal_solve(c->stream, c->d_foc_red, c->d_intr0, c->d_fail, c->width, c->height, aspect));
+    double *h_intr = reinterpret_cast<double *>(c->h_st);   // pinned staging
+    HIPCHK(hipMemcpyAsync(h_intr, c->d_intr0, sizeof(double) * 9, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_flags, c->d_fail, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->h_st->status != 0) return fail(CCAL_E_DEGENERATE, "ccal_init_intrinsics: homography estimation failed");
-    for (int a = 0; a < 9; a++) c->intr0[a] = c->h_st->intr_prev[a];
+    if (c->h_flags[1] != 0) return fail(CCAL_E_DEGENERATE, "ccal_init_intrinsics: homography estimation failed");
+    for (int a = 0; a < 9; a++) c->intr0[a] = h_intr[a];
     for (int a = 0; a < 4; a++)
         if (!std::isfinite(c->intr0[a])) return fail(CCAL_E_DEGENERATE, "ccal_init_intrinsics: non-finite focal length");
     c->have_intr = true;
@@ -339,12 +353,8 @@ int ccal_init_extrinsics(ccal_ctx *c) {
     if (!c->planar_z0) return fail(CCAL_E_NONPLANAR, "ccal_init_extrinsics: only planar z = 0 templates are supported");
     HIPCHK(hipSetDevice(c->device));
     const double t0 = now_s();
-    LmState &s = *c->h_st;
-    host_state_defaults(c, s);
-    for (int a = 0; a < 9; a++) s.intr_prev[a] = c->intr0[a];
-    HIPCHK(hipMemcpyAsync(c->d_st, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->d_fail, 0, sizeof(int) * 4, c->stream));
-    HIPCHK(launch_init_extrinsics(c->stream, c->d_obj, c->d_img, c->d_st, c->d_ext0, c->d_fail, c->N, c->P));
+    HIPCHK(launch_init_extrinsics(c->stream, c->d_obj, c->d_img, c->d_intr0, c->d_ext0, c->d_fail, c->N, c->P));
     HIPCHK(hipMemcpyAsync(c->h_flags, c->d_fail, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->stats.t_init_extr_s = now_s() - t0;
@@ -357,21 +367,41 @@ int ccal_init_extrinsics(ccal_ctx *c) {
 }
 
 // ---- A6-A9: global LM ------------------------------------------------------------------
-static int enqueue_trial(ccal_ctx *c) {
+static int enqueue_trial(ccal_ctx *c, hipStream_t stream) {
     const bool timed = c->time_sweeps && c->ev_used < MAX_KINDS;
-    if (timed) HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], c->stream));
-    HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_ext, c->d_blk, c->d_st, c->d_partials, nullptr, c->N,
-                           c->P));
-    if (timed) HIPCHK(hipEventRecord(c->ev[2 * c->ev_used++ + 1], c->stream));
+    if (timed) HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], stream));
+    HIPCHK(launch_lm_sweep(stream, c->d_obj, c->d_img, c->d_ext, c->d_blk, c->d_st, c->d_partials, nullptr, c->N, c->P));
+    if (timed) HIPCHK(hipEventRecord(c->ev[2 * c->ev_used++ + 1], stream));
     const int nb = lm_sweep_blocks(c->N);
     if (c->world > 1 && c->ar_fn) {
-        HIPCHK(launch_lm_solve(c->stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nb, 1, 0));
+        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nb, 1, 0));
         const int rc = run_allreduce(c, c->d_red, NRED);
         if (rc) return rc;
-        HIPCHK(launch_lm_solve(c->stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nb, 0, 1));
+        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nb, 0, 1));
     } else {
-        HIPCHK(launch_lm_solve(c->stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nb, 1, 1));
+        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nb, 1, 1));
     }
+    return CCAL_OK;
+}
+
+// Capture [begin] + lm_batch trials + state read-back into an executable graph.
+static int capture_graph(ccal_ctx *c, bool with_begin, hipGraphExec_t *out) {
+    hipGraph_t graph = nullptr;
+    hipStream_t cs = c->own_stream;
+    HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    int rc = CCAL_OK;
+    hipError_t e = hipSuccess;
+    if (with_begin) e = launch_lm_begin(cs, c->d_st, make_init(c), c->d_intr0, c->d_ext0, c->d_ext);
+    for (int b = 0; b < c->lm_batch && e == hipSuccess && rc == CCAL_OK; b++) rc = enqueue_trial(c, cs);
+    if (e == hipSuccess && rc == CCAL_OK)
+        e = hipMemcpyAsync(c->h_st, c->d_st, sizeof(LmState), hipMemcpyDeviceToHost, cs);
+    const hipError_t e2 = hipStreamEndCapture(cs, &graph);
+    if (rc != CCAL_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    HIPCHK(e);
+    HIPCHK(e2);
+    if (*out) { (void)hipGraphExecDestroy(*out); *out = nullptr; }
+    HIPCHK(hipGraphInstantiate(out, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
     return CCAL_OK;
 }
 
@@ -381,33 +411,42 @@ int ccal_lm_run(ccal_ctx *c) {
         return fail(CCAL_E_STATE, "ccal_lm_run: initial intrinsics / extrinsics / image points not set");
     HIPCHK(hipSetDevice(c->device));
     const double t0 = now_s();
-    LmState &s = *c->h_st;
-    host_state_defaults(c, s);
-    for (int a = 0; a < 9; a++) s.intr_prev[a] = c->intr0[a];
-    if (c->flags & CCAL_ZERO_TANGENT_DIST) s.intr_prev[6] = s.intr_prev[7] = 0.0;
-    if (s.aspect > 0.0) s.intr_prev[0] = s.aspect * s.intr_prev[1];
-    for (int a = 0; a < 9; a++) s.intr_cand[a] = s.intr_prev[a];
-    HIPCHK(hipMemcpyAsync(c->d_st, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
-    // the loop starts from the stored initial poses (a fit can be re-run from the same start)
-    HIPCHK(hipMemcpyAsync(c->d_ext, c->d_ext0, sizeof(double) * (size_t)c->N * EXT, hipMemcpyDeviceToDevice, c->stream));
     // upper bound on trials: every accepted iteration may be preceded by lambda climbing
     // from -16 to 16 (rejections + re-Schur passes)
     const long max_trials = 8L + (long)c->max_iter * 70L;
     long trials = 0;
     c->ev_used = 0;
-    c->h_flags[0] = 0;
-    while (trials < max_trials) {
-        for (int b = 0; b < c->lm_batch; b++) {
-            const int rc = enqueue_trial(c);
-            if (rc) return rc;
-        }
-        trials += c->lm_batch;
-        HIPCHK(hipMemcpyAsync(c->h_flags, &c->d_st->done, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->h_st->done = 0;
+    const bool graphed = c->use_graph && !c->time_sweeps && !(c->world > 1 && c->ar_fn);
+    if (graphed && c->graph_dirty) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (c->h_flags[0]) break;
+        int rc = capture_graph(c, true, &c->g_first);
+        if (rc == CCAL_OK) rc = capture_graph(c, false, &c->g_cont);
+        if (rc) return rc;
+        c->graph_dirty = false;
     }
-    HIPCHK(hipMemcpyAsync(c->h_st, c->d_st, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (graphed) {
+        HIPCHK(hipGraphLaunch(c->g_first, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        trials += c->lm_batch;
+        while (!c->h_st->done && trials < max_trials) {
+            HIPCHK(hipGraphLaunch(c->g_cont, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            trials += c->lm_batch;
+        }
+    } else {
+        HIPCHK(launch_lm_begin(c->stream, c->d_st, make_init(c), c->d_intr0, c->d_ext0, c->d_ext));
+        while (trials < max_trials) {
+            for (int b = 0; b < c->lm_batch; b++) {
+                const int rc = enqueue_trial(c, c->stream);
+                if (rc) return rc;
+            }
+            trials += c->lm_batch;
+            HIPCHK(hipMemcpyAsync(c->h_st, c->d_st, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (c->h_st->done) break;
+        }
+    }
     const LmState &r = *c->h_st;
     c->stats.t_lm_s = now_s() - t0;
     c->stats.iters = r.iters; c->stats.sweeps = r.sweeps; c->stats.reschur = r.reschur;
@@ -623,20 +662,14 @@ int ccal_debug_image_grams(ccal_ctx *c, const double intr[CCAL_NINTR], const dou
     HIPCHK(hipSetDevice(c->device));
     int rc = ccal_set_extrinsics(c, rt_host);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(c->d_ext, c->d_ext0, sizeof(double) * (size_t)c->N * EXT, hipMemcpyDeviceToDevice, c->stream));
     if (!c->d_gram) HIPCHK(hipMalloc(&c->d_gram, sizeof(double) * c->n_cap * 256));
-    LmState &s = *c->h_st;
-    double keep[9];
-    memcpy(keep, c->intr0, sizeof keep);
-    memcpy(c->intr0, intr, sizeof keep);
-    host_state_defaults(c, s);
-    memcpy(c->intr0, keep, sizeof keep);
-    for (int a = 0; a < 9; a++) s.intr_prev[a] = intr[a];
-    HIPCHK(hipMemcpyAsync(c->d_st_scratch, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_intr_scratch, intr, sizeof(double) * 9, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_lm_begin(c->stream, c->d_st_scratch, make_init(c), c->d_intr_scratch, c->d_ext0, c->d_ext));
     HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_ext, c->d_blk, c->d_st_scratch, c->d_partials,
                            c->d_gram, c->N, c->P));
     HIPCHK(hipMemcpyAsync(G_host, c->d_gram, sizeof(double) * (size_t)c->N * 256, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->have_result = false;
     return CCAL_OK;
 }
 
@@ -645,17 +678,13 @@ int ccal_time_sweep(ccal_ctx *c, int32_t reps, double *avg_us) {
     if (!c->have_problem || !c->have_img || !c->have_intr || !c->have_ext)
         return fail(CCAL_E_STATE, "ccal_time_sweep: needs image points and a parameter point");
     HIPCHK(hipSetDevice(c->device));
-    LmState s;
-    host_state_defaults(c, s);
+    // evaluate at the last result if there is one, else at the initial values
+    const double *intr = c->d_intr0, *ext_src = c->d_ext0;
     if (c->have_result) {
-        for (int a = 0; a < 9; a++) s.intr_prev[a] = c->h_st->intr_prev[a];
-        s.parity = c->h_st->parity;
-    } else {
-        for (int a = 0; a < 9; a++) s.intr_prev[a] = c->intr0[a];
-        HIPCHK(hipMemcpyAsync(c->d_ext, c->d_ext0, sizeof(double) * (size_t)c->N * EXT, hipMemcpyDeviceToDevice,
-                              c->stream));
+        intr = reinterpret_cast<const double *>(reinterpret_cast<const char *>(c->d_st) + offsetof(LmState, intr_prev));
+        ext_src = c->d_ext + (size_t)c->h_st->parity * c->N * EXT;
     }
-    HIPCHK(hipMemcpyAsync(c->d_st_scratch, &s, sizeof s, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_lm_begin(c->stream, c->d_st_scratch, make_init(c), intr, ext_src, c->d_ext));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
@@ -672,6 +701,7 @@ int ccal_time_sweep(ccal_ctx *c, int32_t reps, double *avg_us) {
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    c->have_result = false;   // ext[0] / blk[0] now hold the timed point, not the fit's buffers
     *avg_us = 1000.0 * ms / reps;
     return CCAL_OK;
 }

@@ -354,26 +354,34 @@ __global__ __launch_bounds__(64) void k_init_homography(const float *__restrict_
     }
 }
 
-__global__ __launch_bounds__(64) void k_init_focal_reduce(const double *__restrict__ foc, double *__restrict__ red,
-                                                           int N) {
-    const int j = threadIdx.x;
-    if (j >= NFOC) return;
+__global__ __launch_bounds__(1024) void k_init_focal_reduce(const double *__restrict__ foc, double *__restrict__ red,
+                                                             int N) {
+    // 128 slices x NFOC columns; slice sums are combined in a fixed order (deterministic)
+    __shared__ double part[128][NFOC];
+    const int j = threadIdx.x % NFOC, c = threadIdx.x / NFOC;
     double s = 0.0;
-    for (int i = 0; i < N; i++) s += foc[(size_t)NFOC * i + j];    // fixed order
-    red[j] = s;
+    for (int i = c; i < N; i += 128) s += foc[(size_t)NFOC * i + j];
+    part[c][j] = s;
+    __syncthreads();
+    if (threadIdx.x < NFOC) {
+        double t = 0.0;
+        for (int k = 0; k < 128; k++) t += part[k][threadIdx.x];
+        red[threadIdx.x] = t;
+    }
 }
 
-__global__ __launch_bounds__(64) void k_init_focal_solve(const double *__restrict__ red, LmState *st, int width,
-                                                          int height, double aspect) {
+__global__ __launch_bounds__(64) void k_init_focal_solve(const double *__restrict__ red, double *__restrict__ intr0,
+                                                          int *__restrict__ fail_count, int width, int height,
+                                                          double aspect) {
     if (threadIdx.x != 0) return;
     // cvSolve(A, b, f, CV_NORMAL + CV_SVD): 2x2 normal equations
     double A[3] = {red[0], red[1], red[2]}, f[2] = {red[3], red[4]};
-    int status = red[5] > 0.0 ? -3 : 0;
+    int bad = red[5] > 0.0 ? 1 : 0;
     if (chol_packed<2>(A)) {
         fwd_subst<2>(A, f);
         bwd_subst<2>(A, f);
     } else {
-        status = -3;
+        bad = 1;
     }
     double fx = sqrt(fabs(1.0 / f[0])), fy = sqrt(fabs(1.0 / f[1]));
     if (aspect != 0.0) {
@@ -381,12 +389,12 @@ __global__ __launch_bounds__(64) void k_init_focal_solve(const double *__restric
         fx = aspect * tf;
         fy = tf;
     }
-    st->intr_prev[0] = fx;
-    st->intr_prev[1] = fy;
-    st->intr_prev[2] = !width ? 0.5 : (width - 1) * 0.5;
-    st->intr_prev[3] = !height ? 0.5 : (height - 1) * 0.5;
-    for (int a = 4; a < 9; a++) st->intr_prev[a] = 0.0;
-    st->status = status;
+    intr0[0] = fx;
+    intr0[1] = fy;
+    intr0[2] = !width ? 0.5 : (width - 1) * 0.5;
+    intr0[3] = !height ? 0.5 : (height - 1) * 0.5;
+    for (int a = 4; a < 9; a++) intr0[a] = 0.0;
+    fail_count[1] = bad;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -478,7 +486,7 @@ __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int
 }
 
 __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict__ obj, const float *__restrict__ img,
-                                                         const LmState *__restrict__ st, double *__restrict__ ext,
+                                                         const double *__restrict__ intr0, double *__restrict__ ext,
                                                          int *__restrict__ fail_count, int N, int P) {
     __shared__ __attribute__((aligned(16))) double s_tile[TILE_D];
     __shared__ __attribute__((aligned(16))) double s_G[256];
@@ -491,7 +499,7 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
     bool distorted = false;
 #pragma unroll
     for (int a = 0; a < NINTR; a++) {
-        pts.in[a] = st->intr_prev[a];
+        pts.in[a] = intr0[a];
         if (a >= 4 && pts.in[a] != 0.0) distorted = true;
     }
     pts.distorted = distorted;
@@ -603,17 +611,18 @@ hipError_t launch_init_homography(hipStream_t stream, const float *obj, const fl
     return hipGetLastError();
 }
 hipError_t launch_init_focal_reduce(hipStream_t stream, const double *foc_partials, double *foc_red, int N) {
-    hipLaunchKernelGGL(k_init_focal_reduce, dim3(1), dim3(64), 0, stream, foc_partials, foc_red, N);
+    hipLaunchKernelGGL(k_init_focal_reduce, dim3(1), dim3(1024), 0, stream, foc_partials, foc_red, N);
     return hipGetLastError();
 }
-hipError_t launch_init_focal_solve(hipStream_t stream, const double *foc_red, LmState *st, int width, int height,
-                                   double aspect) {
-    hipLaunchKernelGGL(k_init_focal_solve, dim3(1), dim3(64), 0, stream, foc_red, st, width, height, aspect);
+hipError_t launch_init_focal_solve(hipStream_t stream, const double *foc_red, double *intr0, int *fail_count,
+                                   int width, int height, double aspect) {
+    hipLaunchKernelGGL(k_init_focal_solve, dim3(1), dim3(64), 0, stream, foc_red, intr0, fail_count, width, height,
+                       aspect);
     return hipGetLastError();
 }
-hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const float *img, const LmState *st,
+hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const float *img, const double *intr0,
                                   double *ext, int *fail_count, int N, int P) {
-    hipLaunchKernelGGL(k_init_extrinsics, dim3(N), dim3(64), 0, stream, obj, img, st, ext, fail_count, N, P);
+    hipLaunchKernelGGL(k_init_extrinsics, dim3(N), dim3(64), 0, stream, obj, img, intr0, ext, fail_count, N, P);
     return hipGetLastError();
 }
 

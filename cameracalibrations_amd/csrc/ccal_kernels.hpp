@@ -9,6 +9,8 @@ namespace ccal {
 
 // ccal_lm.hip
 int lm_sweep_blocks(int N);
+hipError_t launch_lm_begin(hipStream_t stream, LmState *st, const LmInit &init, const double *intr0, const double *ext0,
+                           double *ext);
 hipError_t launch_lm_sweep(hipStream_t stream, const float *obj, const float *img, double *ext, double *blk,
                            const LmState *st, double *partials, double *gram_out, int N, int P);
 hipError_t launch_lm_solve(hipStream_t stream, LmState *st, const double *partials, double *red, TraceRec *trace,
@@ -19,9 +21,9 @@ constexpr int NFOC = 8;   // doubles all-reduced for the focal least squares: At
 hipError_t launch_init_homography(hipStream_t stream, const float *obj, const float *img, double *H_out,
                                   double *foc_partials, int N, int P, int width, int height);
 hipError_t launch_init_focal_reduce(hipStream_t stream, const double *foc_partials, double *foc_red, int N);
-hipError_t launch_init_focal_solve(hipStream_t stream, const double *foc_red, LmState *st, int width, int height,
-                                   double aspect);
-hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const float *img, const LmState *st,
+hipError_t launch_init_focal_solve(hipStream_t stream, const double *foc_red, double *intr0, int *fail_count,
+                                   int width, int height, double aspect);
+hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const float *img, const double *intr0,
                                   double *ext, int *fail_count, int N, int P);
 
 // ccal_maps.hip -- RowCol <-> XYZ maps and the four RMS metrics

@@ -230,26 +230,52 @@ __device__ void lm_trace(LmState *st, TraceRec *trace, double err, double rel, i
     st->n_trace++;
 }
 
-__global__ __launch_bounds__(128) void k_lm_solve(LmState *st, const double *__restrict__ partials,
-                                                   double *red, TraceRec *trace, int nblocks,
-                                                   int do_reduce, int do_solve) {
+constexpr int SOLVE_THREADS = 1024;
+constexpr int SOLVE_SLICES = SOLVE_THREADS / 128;
+constexpr int STATE_WORDS = sizeof(LmState) / 8;
+static_assert(sizeof(LmState) % 8 == 0, "LmState is copied as 8-byte words");
+
+__device__ void lm_advance(LmState *st, const double *rs, TraceRec *trace);
+
+// One workgroup.  The partial sums are added by 8 slices x 112 columns with independent
+// (pipelined) loads and combined in a fixed order; the state is staged through LDS so the
+// serial state machine never waits on global memory.
+__global__ __launch_bounds__(SOLVE_THREADS) void k_lm_solve(LmState *st, const double *__restrict__ partials,
+                                                             double *red, TraceRec *trace, int nblocks,
+                                                             int do_reduce, int do_solve) {
+    __shared__ double part[SOLVE_SLICES][128];
     __shared__ double rs[NRED];
+    __shared__ LmState ls;
     if (st->done) return;
     const int tid = threadIdx.x;
-    if (tid < NRED) {
-        double s;
-        if (do_reduce) {
-            s = 0.0;
-            for (int b = 0; b < nblocks; b++) s += partials[(size_t)b * NRED + tid];   // fixed order
-            red[tid] = s;
-        } else {
-            s = red[tid];
+    for (int i = tid; i < STATE_WORDS; i += SOLVE_THREADS)
+        reinterpret_cast<double *>(&ls)[i] = reinterpret_cast<const double *>(st)[i];
+    if (do_reduce) {
+        const int j = tid & 127, c = tid >> 7;
+        double s = 0.0;
+        if (j < NRED)
+            for (int b = c; b < nblocks; b += SOLVE_SLICES) s += partials[(size_t)b * NRED + j];
+        part[c][j] = s;
+        __syncthreads();
+        if (tid < NRED) {
+            double t = part[0][tid];
+#pragma unroll
+            for (int k = 1; k < SOLVE_SLICES; k++) t += part[k][tid];   // fixed order
+            red[tid] = t;
+            rs[tid] = t;
         }
-        rs[tid] = s;
+    } else if (tid < NRED) {
+        rs[tid] = red[tid];
     }
     __syncthreads();
-    if (!do_solve || tid != 0) return;
+    if (!do_solve) return;
+    if (tid == 0) lm_advance(&ls, rs, trace);
+    __syncthreads();
+    for (int i = tid; i < STATE_WORDS; i += SOLVE_THREADS)
+        reinterpret_cast<double *>(st)[i] = reinterpret_cast<const double *>(&ls)[i];
+}
 
+__device__ void lm_advance(LmState *st, const double *rs, TraceRec *trace) {
     // ---- [OCV-K CvLevMarq::updateAlt], SURVEY.md A.6, fused with the next step() ----
     const int mode = st->mode;
     const double err = rs[RED_ERR];
@@ -357,8 +383,54 @@ __global__ __launch_bounds__(128) void k_lm_solve(LmState *st, const double *__r
 }
 
 // ---------------------------------------------------------------------------------------
+// begin: (re)build the LM state on the device and restore the initial poses
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lm_begin(LmState *st, LmInit init, const double *__restrict__ intr0,
+                                                   const double *__restrict__ ext0, double *__restrict__ ext) {
+    const int tid = threadIdx.x;
+    const size_t n = (size_t)init.N_local * EXT;
+    if (ext != ext0)
+        for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n; i += (size_t)gridDim.x * 256) ext[i] = ext0[i];
+    if (blockIdx.x != 0) return;
+    __shared__ LmState ls;
+    for (int i = tid; i < STATE_WORDS; i += 256) reinterpret_cast<double *>(&ls)[i] = 0.0;
+    __syncthreads();
+    if (tid == 0) {
+        ls.mode = MODE_INIT;
+        ls.lambda_lg10 = -3;
+        ls.lg_partials = -3;
+        ls.lam_next = pow10_lg(-3);
+        ls.lam_step = ls.lam_next;
+        ls.max_iter = init.max_iter;
+        ls.eps = init.eps;
+        ls.max_trace = init.max_trace;
+        ls.P = init.P;
+        ls.N_local = init.N_local;
+        ls.nblocks = init.nblocks;
+        ls.N_global = init.N_global;
+        for (int a = 0; a < 9; a++) { ls.mask[a] = init.mask[a]; ls.intr_prev[a] = intr0[a]; }
+        ls.aspect = init.aspect_from_guess ? intr0[0] / intr0[1] : init.aspect;
+        // [OCV-K cvCalibrateCamera2Internal]: p1 = p2 = 0 under ZERO_TANGENT_DIST; fx = aspect * fy
+        if (init.zero_tangent) ls.intr_prev[6] = ls.intr_prev[7] = 0.0;
+        if (ls.aspect > 0.0) ls.intr_prev[0] = ls.aspect * ls.intr_prev[1];
+        for (int a = 0; a < 9; a++) ls.intr_cand[a] = ls.intr_prev[a];
+    }
+    __syncthreads();
+    for (int i = tid; i < STATE_WORDS; i += 256)
+        reinterpret_cast<double *>(st)[i] = reinterpret_cast<const double *>(&ls)[i];
+}
+
+// ---------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------
+hipError_t launch_lm_begin(hipStream_t stream, LmState *st, const LmInit &init, const double *intr0, const double *ext0,
+                           double *ext) {
+    const int blocks = (int)((((size_t)init.N_local * EXT) + 255) / 256);
+    hipLaunchKernelGGL(k_lm_begin, dim3(blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks)), dim3(256), 0, stream, st, init,
+                       intr0, ext0, ext);
+    return hipGetLastError();
+}
+
 int lm_sweep_blocks(int N) { return (N + WAVES - 1) / WAVES; }
 
 hipError_t launch_lm_sweep(hipStream_t stream, const float *obj, const float *img, double *ext, double *blk,
@@ -370,7 +442,7 @@ hipError_t launch_lm_sweep(hipStream_t stream, const float *obj, const float *im
 
 hipError_t launch_lm_solve(hipStream_t stream, LmState *st, const double *partials, double *red, TraceRec *trace,
                            int nblocks, int do_reduce, int do_solve) {
-    hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(128), 0, stream, st, partials, red, trace, nblocks, do_reduce,
+    hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(SOLVE_THREADS), 0, stream, st, partials, red, trace, nblocks, do_reduce,
                        do_solve);
     return hipGetLastError();
 }

@@ -63,6 +63,19 @@ struct LmState {
     int32_t kinds[MAX_KINDS];   // per trial: 1 + mode of the sweep it ran (0 = no-op after `done`)
 };
 
+// Everything k_lm_begin needs to (re)build LmState on the device; passed by value as a kernel
+// argument so that a whole solve (begin + trials + read-back) is one replayable hipGraph.
+struct LmInit {
+    int32_t max_iter, max_trace, P, N_local, nblocks;
+    int32_t zero_tangent;      // CALIB_ZERO_TANGENT_DIST: p1 = p2 = 0
+    int32_t aspect_from_guess; // FIX_ASPECT_RATIO with USE_INTRINSIC_GUESS: aspect = fx0 / fy0
+    int32_t pad_;
+    int64_t N_global;
+    double eps, aspect;
+    int32_t mask[9];
+    int32_t pad2_;
+};
+
 struct TraceRec {          // mirrors ccal_trace in include/ccal.h
     double err, rel_step;
     int32_t accepted, lambda_lg10, iters, pad;
