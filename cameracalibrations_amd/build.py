@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["ccal_lm.hip", "ccal_init.hip", "ccal_maps.hip", "ccal_api.hip"]
 HEADERS = ["ccal_math.hpp", "ccal_state.hpp", "ccal_wave.hpp", "ccal_kernels.hpp", "../../include/ccal.h"]
 LIB = os.path.join(HERE, "libccal_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"]
 
 
 def _stale(target, deps):

@@ -77,7 +77,7 @@ struct ccal_ctx {
     int ev_used = 0;
     // one solve = one replayable graph: begin + lm_batch x (sweep, solve) + state read-back
     hipGraphExec_t g_first = nullptr, g_cont = nullptr;
-    bool graph_dirty = true, use_graph = true;
+    bool graph_dirty = true, use_graph = true, adaptive_batch = true;
 };
 
 static void free_problem_buffers(ccal_ctx *c) {
@@ -132,7 +132,7 @@ int ccal_create(int device, ccal_ctx **out) {
     HIPCHK(hipHostMalloc(&c->h_st, sizeof(LmState), hipHostMallocDefault));
     HIPCHK(hipHostMalloc(&c->h_flags, sizeof(int) * 16, hipHostMallocDefault));
     const char *b = getenv("CCAL_LM_BATCH");
-    if (b && atoi(b) > 0) c->lm_batch = atoi(b);
+    if (b && atoi(b) > 0) { c->lm_batch = atoi(b); c->adaptive_batch = false; }
     const char *g = getenv("CCAL_NO_GRAPH");
     if (g && atoi(g) != 0) c->use_graph = false;
     *out = c;
@@ -374,17 +374,18 @@ static int enqueue_trial(ccal_ctx *c, hipStream_t stream) {
     if (timed) HIPCHK(hipEventRecord(c->ev[2 * c->ev_used++ + 1], stream));
     const int nb = lm_sweep_blocks(c->N);
     if (c->world > 1 && c->ar_fn) {
-        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nb, 1, 0));
+        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nullptr, nb, 1, 0));
         const int rc = run_allreduce(c, c->d_red, NRED);
         if (rc) return rc;
-        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nb, 0, 1));
+        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, c->h_st, nb, 0, 1));
     } else {
-        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nb, 1, 1));
+        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, c->h_st, nb, 1, 1));
     }
     return CCAL_OK;
 }
 
-// Capture [begin] + lm_batch trials + state read-back into an executable graph.
+// Capture [begin] + lm_batch trials into an executable graph.  The terminating k_lm_solve writes
+// the final state straight into the pinned host mirror, so there is no copy node.
 static int capture_graph(ccal_ctx *c, bool with_begin, hipGraphExec_t *out) {
     hipGraph_t graph = nullptr;
     hipStream_t cs = c->own_stream;
@@ -393,8 +394,6 @@ static int capture_graph(ccal_ctx *c, bool with_begin, hipGraphExec_t *out) {
     hipError_t e = hipSuccess;
     if (with_begin) e = launch_lm_begin(cs, c->d_st, make_init(c), c->d_intr0, c->d_ext0, c->d_ext);
     for (int b = 0; b < c->lm_batch && e == hipSuccess && rc == CCAL_OK; b++) rc = enqueue_trial(c, cs);
-    if (e == hipSuccess && rc == CCAL_OK)
-        e = hipMemcpyAsync(c->h_st, c->d_st, sizeof(LmState), hipMemcpyDeviceToHost, cs);
     const hipError_t e2 = hipStreamEndCapture(cs, &graph);
     if (rc != CCAL_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     HIPCHK(e);
@@ -442,7 +441,6 @@ int ccal_lm_run(ccal_ctx *c) {
                 if (rc) return rc;
             }
             trials += c->lm_batch;
-            HIPCHK(hipMemcpyAsync(c->h_st, c->d_st, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(hipStreamSynchronize(c->stream));
             if (c->h_st->done) break;
         }
@@ -470,6 +468,12 @@ int ccal_lm_run(ccal_ctx *c) {
     }
     if (!r.done) return fail(CCAL_E_STATE, "ccal_lm_run: trial budget exhausted without termination");
     c->have_result = true;
+    // size the next graph to the trials this problem needed (no-op launches after `done` cost
+    // a kernel boundary each); a different problem simply continues with g_cont
+    if (graphed && c->adaptive_batch && r.trials != c->lm_batch) {
+        c->lm_batch = r.trials < 2 ? 2 : (r.trials > 32 ? 32 : r.trials);
+        c->graph_dirty = true;
+    }
     if (r.status == -4) return fail(CCAL_E_NONFINITE, "ccal_lm_run: non-finite reprojection error on the device");
     if (r.status == -3) return fail(CCAL_E_DEGENERATE, "ccal_lm_run: reduced intrinsic system not positive definite");
     return r.status == 1 ? CCAL_W_MAX_ITER : CCAL_OK;

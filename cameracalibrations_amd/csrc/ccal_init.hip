@@ -145,9 +145,10 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *tile, doub
         for (int k = 0; k < 36; k++) Ap[k] = A[k];
 #pragma unroll
         for (int a = 0; a < 8; a++) { Ap[tri(a, a)] += lambda * D[a]; d[a] = v[a]; }
-        if (!chol_packed<8>(Ap)) break;                 // degenerate normal equations: keep the current H
-        fwd_subst<8>(Ap, d);
-        bwd_subst<8>(Ap, d);
+        double ipv[8];
+        if (!chol_packed<8>(Ap, ipv)) break;            // degenerate normal equations: keep the current H
+        fwd_subst<8>(Ap, ipv, d);
+        bwd_subst<8>(Ap, ipv, d);
 #pragma unroll
         for (int a = 0; a < 8; a++) xd[a] = x[a] - d[a];
         double rdmax;
@@ -174,14 +175,14 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *tile, doub
                 double L[36];
 #pragma unroll
                 for (int k = 0; k < 36; k++) L[k] = A[k];
-                double maxval = DBL_EPS;
-                if (chol_packed<8>(L)) {
+                double maxval = DBL_EPS, ipl[8];
+                if (chol_packed<8>(L, ipl)) {
 #pragma unroll
                     for (int a = 0; a < 8; a++) {
                         double e[8];
 #pragma unroll
                         for (int b = 0; b < 8; b++) e[b] = (a == b) ? 1.0 : 0.0;
-                        fwd_subst<8>(L, e);
+                        fwd_subst<8>(L, ipl, e);
                         double s2 = 0.0;
 #pragma unroll
                         for (int b = 0; b < 8; b++) s2 += e[b] * e[b];
@@ -265,13 +266,14 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *tile, d
     const double mu_shift = 1e-11 * trace;
 #pragma unroll
     for (int a = 0; a < 9; a++) A[tri(a, a)] += mu_shift;
-    if (!chol_packed<9>(A)) return false;
+    double ipa[9];
+    if (!chol_packed<9>(A, ipa)) return false;
     double hv[9];
 #pragma unroll
     for (int a = 0; a < 9; a++) hv[a] = 1.0 / 3.0;
     for (int it = 0; it < 12; it++) {
-        fwd_subst<9>(A, hv);
-        bwd_subst<9>(A, hv);
+        fwd_subst<9>(A, ipa, hv);
+        bwd_subst<9>(A, ipa, hv);
         double nrm = 0.0;
 #pragma unroll
         for (int a = 0; a < 9; a++) nrm += hv[a] * hv[a];
@@ -377,9 +379,10 @@ __global__ __launch_bounds__(64) void k_init_focal_solve(const double *__restric
     // cvSolve(A, b, f, CV_NORMAL + CV_SVD): 2x2 normal equations
     double A[3] = {red[0], red[1], red[2]}, f[2] = {red[3], red[4]};
     int bad = red[5] > 0.0 ? 1 : 0;
-    if (chol_packed<2>(A)) {
-        fwd_subst<2>(A, f);
-        bwd_subst<2>(A, f);
+    double ip2[2];
+    if (chol_packed<2>(A, ip2)) {
+        fwd_subst<2>(A, ip2, f);
+        bwd_subst<2>(A, ip2, f);
     } else {
         bad = 1;
     }
@@ -582,9 +585,10 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
 #pragma unroll
             for (int k = 0; k < 6; k++) d[k] = JtErr[k];
             damp_diag<6>(A, exp((double)lambdaLg10 * log(10.0)));
-            const bool pd = chol_packed<6>(A);
-            fwd_subst<6>(A, d);
-            bwd_subst<6>(A, d);
+            double ip6[6];
+            const bool pd = chol_packed<6>(A, ip6);
+            fwd_subst<6>(A, ip6, d);
+            bwd_subst<6>(A, ip6, d);
 #pragma unroll
             for (int k = 0; k < 6; k++) rt[k] = prev[k] - (pd ? d[k] : 0.0);
         }

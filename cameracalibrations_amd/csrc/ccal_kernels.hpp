@@ -14,7 +14,7 @@ hipError_t launch_lm_begin(hipStream_t stream, LmState *st, const LmInit &init, 
 hipError_t launch_lm_sweep(hipStream_t stream, const float *obj, const float *img, double *ext, double *blk,
                            const LmState *st, double *partials, double *gram_out, int N, int P);
 hipError_t launch_lm_solve(hipStream_t stream, LmState *st, const double *partials, double *red, TraceRec *trace,
-                           int nblocks, int do_reduce, int do_solve);
+                           LmState *host_result, int nblocks, int do_reduce, int do_solve);
 
 // ccal_init.hip -- closed-form initialisation
 constexpr int NFOC = 8;   // doubles all-reduced for the focal least squares: AtA(3) Atb(2) fail(1) pad(2)

@@ -153,10 +153,20 @@ CCAL_HD void point_residual(const double M[3], double u_obs, double v_obs, const
 // packed lower-triangular index, a >= b
 CCAL_HD constexpr int tri(int a, int b) { return a * (a + 1) / 2 + b; }
 
-// In-place Cholesky of a packed lower SPD matrix: A = L L^T.  Returns false when a pivot
-// is not strictly positive (or NaN); the factor is then unusable.
+// 1/sqrt(d): on the device one v_rsq_f64 + refinement (ocml rsqrt), no divide
+CCAL_HD double rsqrt_pos(double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return rsqrt(d);
+#else
+    return 1.0 / sqrt(d);
+#endif
+}
+
+// In-place Cholesky of a packed lower SPD matrix: A = L L^T, inv[j] = 1 / L[j][j].
+// Division-free (reciprocal square roots); the substitutions below multiply by inv.
+// Returns false when a pivot is not strictly positive (or NaN); the factor is then unusable.
 template <int N>
-CCAL_HD bool chol_packed(double A[N * (N + 1) / 2]) {
+CCAL_HD bool chol_packed(double A[N * (N + 1) / 2], double inv[N]) {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -164,15 +174,15 @@ CCAL_HD bool chol_packed(double A[N * (N + 1) / 2]) {
 #pragma unroll
         for (int k = 0; k < j; k++) d -= A[tri(j, k)] * A[tri(j, k)];
         ok = ok && (d > 0.0);
-        const double dj = sqrt(d);
-        const double inv = 1.0 / dj;
-        A[tri(j, j)] = dj;
+        const double r = rsqrt_pos(d);
+        inv[j] = r;
+        A[tri(j, j)] = d * r;
 #pragma unroll
         for (int i = j + 1; i < N; i++) {
             double s = A[tri(i, j)];
 #pragma unroll
             for (int k = 0; k < j; k++) s -= A[tri(i, k)] * A[tri(j, k)];
-            A[tri(i, j)] = s * inv;
+            A[tri(i, j)] = s * r;
         }
     }
     return ok;
@@ -180,24 +190,24 @@ CCAL_HD bool chol_packed(double A[N * (N + 1) / 2]) {
 
 // y = L^-1 b  (forward substitution), in place
 template <int N>
-CCAL_HD void fwd_subst(const double L[N * (N + 1) / 2], double b[N]) {
+CCAL_HD void fwd_subst(const double L[N * (N + 1) / 2], const double inv[N], double b[N]) {
 #pragma unroll
     for (int i = 0; i < N; i++) {
         double s = b[i];
 #pragma unroll
         for (int k = 0; k < i; k++) s -= L[tri(i, k)] * b[k];
-        b[i] = s / L[tri(i, i)];
+        b[i] = s * inv[i];
     }
 }
 // x = L^-T y  (back substitution), in place
 template <int N>
-CCAL_HD void bwd_subst(const double L[N * (N + 1) / 2], double b[N]) {
+CCAL_HD void bwd_subst(const double L[N * (N + 1) / 2], const double inv[N], double b[N]) {
 #pragma unroll
     for (int i = N - 1; i >= 0; i--) {
         double s = b[i];
 #pragma unroll
         for (int k = i + 1; k < N; k++) s -= L[tri(k, i)] * b[k];
-        b[i] = s / L[tri(i, i)];
+        b[i] = s * inv[i];
     }
 }
 

@@ -5,9 +5,11 @@
 //   img      [2,P,N]    f32   observed corners; the only O(N*P) stream: 8 B per corner-residual
 //   ext      [2][N][8]  f64   rvec,tvec (+2 pad) per image, double-buffered: parity p holds the
 //                             last ACCEPTED point ("prev"), 1-p the candidate being evaluated
-//   blk      [2][N][88] f64   per-image normal-equation blocks C (6x6 packed, 21) | B (9x6) | h (6),
-//                             same double-buffering; kept so that a rejected step can be
-//                             re-solved with a larger lambda without another sweep
+//   blk      [2][N][176] f64  per-image normal-equation blocks, same double-buffering:
+//                             raw C (6x6 packed, 21) | B (9x6) | h (6), kept so that a rejected step
+//                             can be re-damped without another sweep, and the damped factor
+//                             L | 1/diag(L) | pd flag | Y = L^-1 [B^T | h] of the lambda the next step
+//                             uses, so that back-substitution needs no second factorisation
 //   partials [nblk][112] f64  per-workgroup partial sums of the reduced intrinsic system
 //   red      [112]      f64   the reduced system (what is all-reduced across GPUs)
 //   LmState             the OpenCV CvLevMarq state machine, advanced on device
@@ -27,11 +29,16 @@ constexpr int RED_DNUM = 109;  // sum ||ext_cand - ext_prev||^2
 constexpr int RED_DDEN = 110;  // sum ||ext_prev||^2
 constexpr int RED_BAD = 111;   // images with a non-PD block or non-finite error
 
-constexpr int BLK = 88;        // per-image block stride (doubles)
-constexpr int BLK_C = 0;       // C packed lower 6x6
+constexpr int BLK = 176;       // per-image block stride (doubles)
+constexpr int BLK_C = 0;       // C packed lower 6x6 (raw, undamped)
 constexpr int BLK_B = 21;      // B[a][k], a = intrinsic slot 0..8, k = extrinsic 0..5
 constexpr int BLK_H = 75;      // h[k]
-constexpr int BLK_USED = 81;
+constexpr int BLK_RAW = 81;    // end of the raw part
+constexpr int BLK_L = 81;      // Cholesky factor of the damped C, packed lower (21)
+constexpr int BLK_INV = 102;   // 1 / diag(L) (6)
+constexpr int BLK_PD = 108;    // 1.0 if the damped block was positive definite
+constexpr int BLK_Y = 112;     // Y[j][k] = (L^-1 col_j)[k], j = 0..8 columns of B^T, j = 9: h  (60)
+constexpr int BLK_USED = 172;
 constexpr int EXT = 8;         // per-image extrinsic stride (doubles)
 
 enum : int { MODE_INIT = 0, MODE_EVAL = 1, MODE_RESCHUR = 2 };
@@ -61,6 +68,7 @@ struct LmState {
     int32_t pad_;
     double A_prev[45], g_prev[9];
     int32_t kinds[MAX_KINDS];   // per trial: 1 + mode of the sweep it ran (0 = no-op after `done`)
+    double pow10[33];           // lambda table 10^(lg), lg = -16..16, filled by k_lm_begin
 };
 
 // Everything k_lm_begin needs to (re)build LmState on the device; passed by value as a kernel
