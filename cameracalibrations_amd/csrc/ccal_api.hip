@@ -5,6 +5,7 @@
 // gfx950 kernels.  There is no CPU fallback: without a HIP device every entry fails.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -19,6 +20,10 @@
 #include "ccal_state.hpp"
 
 using namespace ccal;
+
+#ifdef CCAL_STAMPS
+namespace ccal { hipError_t debug_read_stamps(unsigned long long *out); }
+#endif
 
 static thread_local std::string g_err;
 
@@ -51,7 +56,7 @@ struct ccal_ctx {
     const float *d_img = nullptr;
     size_t img_cap = 0, n_cap = 0;
     int p_cap = 0;
-    double *d_ext = nullptr, *d_ext0 = nullptr, *d_blk = nullptr, *d_partials = nullptr, *d_red = nullptr;
+    double *d_ext0 = nullptr, *d_blk = nullptr, *d_partials = nullptr, *d_red = nullptr;
     double *d_H = nullptr, *d_foc_partials = nullptr, *d_foc_red = nullptr, *d_gram = nullptr;
     int *d_fail = nullptr;
     double *d_intr0 = nullptr, *d_intr_scratch = nullptr;   // initial intrinsics [9] on the device
@@ -77,13 +82,15 @@ struct ccal_ctx {
     int ev_used = 0;
     // one solve = one replayable graph: begin + lm_batch x (sweep, solve) + state read-back
     hipGraphExec_t g_first = nullptr, g_cont = nullptr;
-    bool graph_dirty = true, use_graph = true, adaptive_batch = true;
+    double dbg_enqueue_s = 0, dbg_total_s = 0;
+    int dbg_runs = 0;
+    bool graph_dirty = true, use_graph = true, adaptive_batch = true, spin_wait = true;
 };
 
 static void free_problem_buffers(ccal_ctx *c) {
-    (void)hipFree(c->d_obj); (void)hipFree(c->d_img_own); (void)hipFree(c->d_ext); (void)hipFree(c->d_ext0); (void)hipFree(c->d_blk); (void)hipFree(c->d_partials);
+    (void)hipFree(c->d_obj); (void)hipFree(c->d_img_own); (void)hipFree(c->d_ext0); (void)hipFree(c->d_blk); (void)hipFree(c->d_partials);
     (void)hipFree(c->d_H); (void)hipFree(c->d_foc_partials); (void)hipFree(c->d_gram);
-    c->d_obj = nullptr; c->d_img_own = nullptr; c->d_ext = c->d_ext0 = c->d_blk = c->d_partials = nullptr;
+    c->d_obj = nullptr; c->d_img_own = nullptr; c->d_ext0 = c->d_blk = c->d_partials = nullptr;
     c->d_H = c->d_foc_partials = c->d_gram = nullptr;
     c->img_cap = 0; c->n_cap = 0; c->p_cap = 0;
 }
@@ -135,6 +142,8 @@ int ccal_create(int device, ccal_ctx **out) {
     if (b && atoi(b) > 0) { c->lm_batch = atoi(b); c->adaptive_batch = false; }
     const char *g = getenv("CCAL_NO_GRAPH");
     if (g && atoi(g) != 0) c->use_graph = false;
+    const char *sp = getenv("CCAL_NO_SPIN");
+    if (sp && atoi(sp) != 0) c->spin_wait = false;
     *out = c;
     return CCAL_OK;
 }
@@ -196,7 +205,6 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
         free_problem_buffers(c);
         const size_t n = (size_t)N;
         HIPCHK(hipMalloc(&c->d_obj, sizeof(float) * 3 * P));
-        HIPCHK(hipMalloc(&c->d_ext, sizeof(double) * 2 * n * EXT));
         HIPCHK(hipMalloc(&c->d_ext0, sizeof(double) * n * EXT));
         HIPCHK(hipMalloc(&c->d_blk, sizeof(double) * 2 * n * BLK));
         HIPCHK(hipMalloc(&c->d_partials, sizeof(double) * (size_t)lm_sweep_blocks(N) * NRED));
@@ -206,7 +214,7 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
         c->p_cap = P;
     }
     HIPCHK(hipMemcpyAsync(c->d_obj, obj, sizeof(float) * 3 * P, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_ext, 0, sizeof(double) * 2 * (size_t)N * EXT, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_blk, 0, sizeof(double) * 2 * (size_t)N * BLK, c->stream));
     HIPCHK(hipMemsetAsync(c->d_ext0, 0, sizeof(double) * (size_t)N * EXT, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));   // `obj` may be released by the caller after return
     c->P = P; c->N = N; c->width = width; c->height = height; c->aspect = aspect; c->flags = flags;
@@ -367,19 +375,43 @@ int ccal_init_extrinsics(ccal_ctx *c) {
 }
 
 // ---- A6-A9: global LM ------------------------------------------------------------------
+// (trials << 32) | done, written to pinned host memory by every k_lm_solve that advances the state
+static unsigned long long *progress_word(ccal_ctx *c) { return reinterpret_cast<unsigned long long *>(c->h_flags + 8); }
+
+// Wait until the device reports `done` or `target_trials` executed trials.  Spinning on the
+// pinned progress word avoids the wake-up latency of hipStreamSynchronize (tens of microseconds,
+// comparable to a whole solve); it falls back to a stream synchronisation after ~50 ms.
+static int wait_progress(ccal_ctx *c, long target_trials) {
+    volatile unsigned long long *p = progress_word(c);
+    if (c->spin_wait) {
+        for (long spins = 0; spins < 40000000L; spins++) {
+            const unsigned long long v = *p;
+            if ((v & 1ull) || (long)(v >> 32) >= target_trials) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                return CCAL_OK;
+            }
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CCAL_OK;
+}
+
 static int enqueue_trial(ccal_ctx *c, hipStream_t stream) {
     const bool timed = c->time_sweeps && c->ev_used < MAX_KINDS;
     if (timed) HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], stream));
-    HIPCHK(launch_lm_sweep(stream, c->d_obj, c->d_img, c->d_ext, c->d_blk, c->d_st, c->d_partials, nullptr, c->N, c->P));
+    HIPCHK(launch_lm_sweep(stream, c->d_obj, c->d_img, c->d_blk, c->d_st, c->d_partials, nullptr, c->N, c->P));
     if (timed) HIPCHK(hipEventRecord(c->ev[2 * c->ev_used++ + 1], stream));
     const int nb = lm_sweep_blocks(c->N);
     if (c->world > 1 && c->ar_fn) {
-        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nullptr, nb, 1, 0));
+        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nullptr, nullptr, nb, 1, 0));
         const int rc = run_allreduce(c, c->d_red, NRED);
         if (rc) return rc;
-        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, c->h_st, nb, 0, 1));
+        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, c->h_st, progress_word(c), nb, 0, 1));
     } else {
-        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, c->h_st, nb, 1, 1));
+        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, c->h_st, progress_word(c), nb, 1, 1));
     }
     return CCAL_OK;
 }
@@ -392,7 +424,7 @@ static int capture_graph(ccal_ctx *c, bool with_begin, hipGraphExec_t *out) {
     HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     int rc = CCAL_OK;
     hipError_t e = hipSuccess;
-    if (with_begin) e = launch_lm_begin(cs, c->d_st, make_init(c), c->d_intr0, c->d_ext0, c->d_ext);
+    if (with_begin) e = launch_lm_begin(cs, c->d_st, make_init(c), c->d_intr0, c->d_ext0, EXT, c->d_blk);
     for (int b = 0; b < c->lm_batch && e == hipSuccess && rc == CCAL_OK; b++) rc = enqueue_trial(c, cs);
     const hipError_t e2 = hipStreamEndCapture(cs, &graph);
     if (rc != CCAL_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -416,6 +448,7 @@ int ccal_lm_run(ccal_ctx *c) {
     long trials = 0;
     c->ev_used = 0;
     c->h_st->done = 0;
+    *progress_word(c) = 0ull;
     const bool graphed = c->use_graph && !c->time_sweeps && !(c->world > 1 && c->ar_fn);
     if (graphed && c->graph_dirty) {
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -424,29 +457,38 @@ int ccal_lm_run(ccal_ctx *c) {
         if (rc) return rc;
         c->graph_dirty = false;
     }
+    const double t_enq0 = now_s();
     if (graphed) {
         HIPCHK(hipGraphLaunch(c->g_first, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        c->dbg_enqueue_s += now_s() - t_enq0;
         trials += c->lm_batch;
+        int rc = wait_progress(c, trials);
+        if (rc) return rc;
         while (!c->h_st->done && trials < max_trials) {
             HIPCHK(hipGraphLaunch(c->g_cont, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
             trials += c->lm_batch;
+            if ((rc = wait_progress(c, trials)) != CCAL_OK) return rc;
         }
     } else {
-        HIPCHK(launch_lm_begin(c->stream, c->d_st, make_init(c), c->d_intr0, c->d_ext0, c->d_ext));
+        HIPCHK(launch_lm_begin(c->stream, c->d_st, make_init(c), c->d_intr0, c->d_ext0, EXT, c->d_blk));
         while (trials < max_trials) {
             for (int b = 0; b < c->lm_batch; b++) {
                 const int rc = enqueue_trial(c, c->stream);
                 if (rc) return rc;
             }
+            if (trials == 0) c->dbg_enqueue_s += now_s() - t_enq0;
             trials += c->lm_batch;
-            HIPCHK(hipStreamSynchronize(c->stream));
+            const int rc = wait_progress(c, trials);
+            if (rc) return rc;
             if (c->h_st->done) break;
         }
     }
     const LmState &r = *c->h_st;
     c->stats.t_lm_s = now_s() - t0;
+    c->dbg_total_s += c->stats.t_lm_s;
+    if (++c->dbg_runs == 200 && getenv("CCAL_DEBUG_TIMING"))
+        fprintf(stderr, "[ccal] lm_run x200: enqueue %.2f us, total %.2f us per call (graph %d, batch %d)\n",
+                1e6 * c->dbg_enqueue_s / 200, 1e6 * c->dbg_total_s / 200, (int)graphed, c->lm_batch);
     c->stats.iters = r.iters; c->stats.sweeps = r.sweeps; c->stats.reschur = r.reschur;
     c->stats.rejected = r.rejected; c->stats.lambda_lg10 = r.lambda_lg10; c->stats.n_bad = r.n_bad;
     c->stats.final_err = r.prev_err; c->stats.rel_step = r.rel_step;
@@ -470,7 +512,7 @@ int ccal_lm_run(ccal_ctx *c) {
     c->have_result = true;
     // size the next graph to the trials this problem needed (no-op launches after `done` cost
     // a kernel boundary each); a different problem simply continues with g_cont
-    if (graphed && c->adaptive_batch && r.trials != c->lm_batch) {
+    if (c->adaptive_batch && r.trials != c->lm_batch) {
         c->lm_batch = r.trials < 2 ? 2 : (r.trials > 32 ? 32 : r.trials);
         c->graph_dirty = true;
     }
@@ -497,14 +539,16 @@ int ccal_get_result(ccal_ctx *c, double intr[CCAL_NINTR], double *rvecs, double 
     const LmState &r = *c->h_st;
     if (intr) memcpy(intr, r.intr_prev, sizeof(double) * 9);
     if (rvecs || tvecs) {
-        std::vector<double> e((size_t)c->N * EXT);
-        HIPCHK(hipMemcpyAsync(e.data(), c->d_ext + (size_t)r.parity * c->N * EXT, sizeof(double) * e.size(),
-                              hipMemcpyDeviceToHost, c->stream));
+        // rvec,tvec are the first 6 doubles of each image's block of the accepted parity
+        std::vector<double> e((size_t)c->N * 8);
+        HIPCHK(hipMemcpy2DAsync(e.data(), sizeof(double) * 8, c->d_blk + (size_t)r.parity * c->N * BLK,
+                                sizeof(double) * BLK, sizeof(double) * 8, (size_t)c->N, hipMemcpyDeviceToHost,
+                                c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         for (int i = 0; i < c->N; i++)
             for (int k = 0; k < 3; k++) {
-                if (rvecs) rvecs[(size_t)3 * i + k] = e[(size_t)i * EXT + k];
-                if (tvecs) tvecs[(size_t)3 * i + k] = e[(size_t)i * EXT + 3 + k];
+                if (rvecs) rvecs[(size_t)3 * i + k] = e[(size_t)i * 8 + k];
+                if (tvecs) tvecs[(size_t)3 * i + k] = e[(size_t)i * 8 + 3 + k];
             }
     }
     if (stats) *stats = c->stats;
@@ -668,9 +712,9 @@ int ccal_debug_image_grams(ccal_ctx *c, const double intr[CCAL_NINTR], const dou
     if (rc) return rc;
     if (!c->d_gram) HIPCHK(hipMalloc(&c->d_gram, sizeof(double) * c->n_cap * 256));
     HIPCHK(hipMemcpyAsync(c->d_intr_scratch, intr, sizeof(double) * 9, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(launch_lm_begin(c->stream, c->d_st_scratch, make_init(c), c->d_intr_scratch, c->d_ext0, c->d_ext));
-    HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_ext, c->d_blk, c->d_st_scratch, c->d_partials,
-                           c->d_gram, c->N, c->P));
+    HIPCHK(launch_lm_begin(c->stream, c->d_st_scratch, make_init(c), c->d_intr_scratch, c->d_ext0, EXT, c->d_blk));
+    HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_blk, c->d_st_scratch, c->d_partials, c->d_gram, c->N,
+                           c->P));
     HIPCHK(hipMemcpyAsync(G_host, c->d_gram, sizeof(double) * (size_t)c->N * 256, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_result = false;
@@ -684,21 +728,23 @@ int ccal_time_sweep(ccal_ctx *c, int32_t reps, double *avg_us) {
     HIPCHK(hipSetDevice(c->device));
     // evaluate at the last result if there is one, else at the initial values
     const double *intr = c->d_intr0, *ext_src = c->d_ext0;
+    int stride = EXT;
     if (c->have_result) {
         intr = reinterpret_cast<const double *>(reinterpret_cast<const char *>(c->d_st) + offsetof(LmState, intr_prev));
-        ext_src = c->d_ext + (size_t)c->h_st->parity * c->N * EXT;
+        ext_src = c->d_blk + (size_t)c->h_st->parity * c->N * BLK;
+        stride = BLK;
     }
-    HIPCHK(launch_lm_begin(c->stream, c->d_st_scratch, make_init(c), intr, ext_src, c->d_ext));
+    HIPCHK(launch_lm_begin(c->stream, c->d_st_scratch, make_init(c), intr, ext_src, stride, c->d_blk));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
     for (int w = 0; w < 3; w++)
-        HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_ext, c->d_blk, c->d_st_scratch, c->d_partials,
-                               nullptr, c->N, c->P));
+        HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_blk, c->d_st_scratch, c->d_partials, nullptr, c->N,
+                               c->P));
     HIPCHK(hipEventRecord(e0, c->stream));
     for (int r = 0; r < reps; r++)
-        HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_ext, c->d_blk, c->d_st_scratch, c->d_partials,
-                               nullptr, c->N, c->P));
+        HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_blk, c->d_st_scratch, c->d_partials, nullptr, c->N,
+                               c->P));
     HIPCHK(hipEventRecord(e1, c->stream));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0;
@@ -709,5 +755,13 @@ int ccal_time_sweep(ccal_ctx *c, int32_t reps, double *avg_us) {
     *avg_us = 1000.0 * ms / reps;
     return CCAL_OK;
 }
+
+#ifdef CCAL_STAMPS
+int ccal_debug_stamps(unsigned long long *out) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(ccal::debug_read_stamps(out));
+    return CCAL_OK;
+}
+#endif
 
 }  // extern "C"

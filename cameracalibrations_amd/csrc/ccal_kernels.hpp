@@ -10,11 +10,12 @@ namespace ccal {
 // ccal_lm.hip
 int lm_sweep_blocks(int N);
 hipError_t launch_lm_begin(hipStream_t stream, LmState *st, const LmInit &init, const double *intr0, const double *ext0,
-                           double *ext);
-hipError_t launch_lm_sweep(hipStream_t stream, const float *obj, const float *img, double *ext, double *blk,
-                           const LmState *st, double *partials, double *gram_out, int N, int P);
+                           int ext0_stride, double *blk);
+hipError_t launch_lm_sweep(hipStream_t stream, const float *obj, const float *img, double *blk, const LmState *st,
+                           double *partials, double *gram_out, int N, int P);
 hipError_t launch_lm_solve(hipStream_t stream, LmState *st, const double *partials, double *red, TraceRec *trace,
-                           LmState *host_result, int nblocks, int do_reduce, int do_solve);
+                           LmState *host_result, unsigned long long *host_progress, int nblocks, int do_reduce,
+                           int do_solve);
 
 // ccal_init.hip -- closed-form initialisation
 constexpr int NFOC = 8;   // doubles all-reduced for the focal least squares: AtA(3) Atb(2) fail(1) pad(2)

@@ -31,135 +31,176 @@ namespace ccal {
 
 constexpr int WAVES = 4;             // images per workgroup
 
-// packed-lower index tables
-__device__ const unsigned char TRI6_A[21] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5};
-__device__ const unsigned char TRI6_B[21] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5};
-__device__ const unsigned char TRI10_A[55] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 6, 6, 6, 6, 6, 6, 6,
-                                             7, 7, 7, 7, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9, 9, 9};
-__device__ const unsigned char TRI10_B[55] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5, 6,
-                                             0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7, 8, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9};
+// Diagnostic build only (-DCCAL_STAMPS): s_memtime stamps of one wave at the phase boundaries
+// of the sweep, read back through ccal_debug_stamps().  No stamp executes in the product build.
+#ifdef CCAL_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define STAMP(i)                                                                              \
+    do {                                                                                      \
+        if (blockIdx.x == 7 && tid == 0) {                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            unsigned long long t_;                                                            \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            g_stamps[i] = t_;                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+        }                                                                                     \
+    } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+// packed-lower decode o -> (a, b), a >= b, for o < 55 (no memory table: arithmetic in the
+// shadow of the first global loads)
+__device__ __forceinline__ void tri_decode(int o, int &a, int &b) {
+    a = (int)((sqrtf(8.0f * (float)o + 1.0f) - 1.0f) * 0.5f);
+    if ((a + 1) * (a + 2) / 2 <= o) a++;
+    if (a * (a + 1) / 2 > o) a--;
+    b = o - a * (a + 1) / 2;
+}
+
+// wave-private LDS carve-up (doubles).  The Gram tile is dead once the MFMAs have issued, so
+// everything after it re-uses the same 17 KB: 4 waves x 17 KB + 3.5 KB = 73 KB per workgroup.
+constexpr int W_G = 0;        // 16 x 16 Gram matrix
+constexpr int W_HEAD = 256;   // 72-double block head (prologue staging, then the new head)
+constexpr int W_Y = 328;      // Y[j][k] = (L^-1 col_j)[k], 10 x 6
+static_assert(W_Y + 60 <= TILE_D, "wave scratch exceeds the tile");
 
 // ---------------------------------------------------------------------------------------
 // sweep
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(WAVES * 64) void k_lm_sweep(const float *__restrict__ obj,
                                                           const float *__restrict__ img,
-                                                          double *__restrict__ ext,
                                                           double *__restrict__ blk,
                                                           const LmState *__restrict__ st,
                                                           double *__restrict__ partials,
                                                           double *__restrict__ gram_out, int N, int P) {
-    __shared__ __attribute__((aligned(16))) double s_tile[WAVES * TILE_D];
-    __shared__ __attribute__((aligned(16))) double s_G[WAVES * 256];
-    __shared__ __attribute__((aligned(16))) double s_Y[WAVES * 64];     // Y (60) | pad
-    __shared__ __attribute__((aligned(16))) double s_L[WAVES * 32];     // L (21) | inv (6) | pd
+    __shared__ __attribute__((aligned(16))) double s_wave[WAVES * TILE_D];
     __shared__ __attribute__((aligned(16))) double s_red[WAVES * NRED];
 
-    if (st->done) return;
     const int tid = threadIdx.x;
+    STAMP(0);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int img_i = blockIdx.x * WAVES + wave;
     const bool active = img_i < N;              // wave-uniform
     const int ii = active ? img_i : N - 1;      // clamped: idle waves mirror the last image, store nothing
+
+    // ---- 0. every load that does not depend on the LM state is issued up front: both parities
+    //         of the block head (rvec,tvec | U | pd) and the first 64 corners ----
+    const double *b0p = blk + (size_t)ii * BLK, *b1p = blk + ((size_t)N + ii) * BLK;
+    const double h0a = b0p[lane], h1a = b1p[lane];
+    const double h0b = lane < 8 ? b0p[64 + lane] : 0.0, h1b = lane < 8 ? b1p[64 + lane] : 0.0;
+    const float2 *img2 = reinterpret_cast<const float2 *>(img) + (size_t)ii * P;
+    const int pc0 = lane < P ? lane : P - 1;
+    float2 uv = img2[pc0];                      // coalesced 8 B per lane
+    float m0 = obj[3 * pc0], m1 = obj[3 * pc0 + 1], m2 = obj[3 * pc0 + 2];
+    int oa[2], ob[2];                           // (a, b) of the packed outputs this lane assembles
+    tri_decode(lane < 45 ? lane : (lane >= 54 ? lane - 54 : 0), oa[0], ob[0]);
+    tri_decode(lane + 64 < RED_SG ? lane + 64 - RED_SC : 0, oa[1], ob[1]);
+
+    if (st->done) return;
+    STAMP(1);
     const int mode = st->mode;
     const int par = st->parity;
-
-    double *tile = s_tile + wave * TILE_D;
-    double *Gs = s_G + wave * 256;
-    double *Ys = s_Y + wave * 64;
-    double *Ls = s_L + wave * 32;
-    double *red = s_red + wave * NRED;
-
-    double dnum = 0.0, dden = 0.0;
     const int cand = (mode == MODE_EVAL) ? 1 - par : par;   // buffer this sweep evaluates / writes
 
-    if (mode != MODE_RESCHUR) {
-        // ---- 1. candidate extrinsics (wave-uniform arithmetic) ----
-        double e6[6];
-        const double *ep = ext + ((size_t)par * N + ii) * EXT;
+    double *W = s_wave + wave * TILE_D;
+    double *Gs = W + W_G, *Hs = W + W_HEAD, *Ys = W + W_Y;
+    double *red = s_red + wave * NRED;
+
+    // ---- 1. block head of the accepted point -> wave-uniform registers ----
+    Hs[lane] = par ? h1a : h0a;
+    if (lane < 8) Hs[64 + lane] = par ? h1b : h0b;
+    wave_lds_sync();
+    double e6[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) e6[k] = ep[k];
+    for (int k = 0; k < 6; k++) e6[k] = Hs[BLK_EXT + k];    // LDS broadcast reads
+    double dnum = 0.0, dden = 0.0;
+
+    if (mode != MODE_RESCHUR) {
         double in[NINTR];
         if (mode == MODE_EVAL) {
-            // delta_i = C_l^-1 (h - B^T delta_int) = L^-T (Y_h - Y_B delta_int), factor from the last sweep
-            const double *bp = blk + ((size_t)par * N + ii) * BLK;
-            double L[21], inv[6], rhs[6];
+            // delta_i = C_l^-1 (h - B^T delta_int) = u_h - U_B delta_int, U kept by the last sweep
+            double d[6];
 #pragma unroll
-            for (int k = 0; k < 21; k++) L[k] = bp[BLK_L + k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) { inv[k] = bp[BLK_INV + k]; rhs[k] = bp[BLK_Y + 54 + k]; }
+            for (int k = 0; k < 6; k++) d[k] = Hs[BLK_U + 54 + k];
 #pragma unroll
             for (int a = 0; a < NINTR; a++) {
-                const double d = st->dint[a];
+                const double da = st->dint[a];
 #pragma unroll
-                for (int k = 0; k < 6; k++) rhs[k] -= bp[BLK_Y + a * 6 + k] * d;
+                for (int k = 0; k < 6; k++) d[k] -= Hs[BLK_U + a * 6 + k] * da;
             }
-            bwd_subst<6>(L, inv, rhs);
-            const bool ok = bp[BLK_PD] != 0.0;
+            const bool ok = Hs[BLK_PD] != 0.0;
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-                const double d = ok ? rhs[k] : 0.0;   // degenerate view: leave its pose unchanged
+                const double dk = ok ? d[k] : 0.0;    // degenerate view: leave its pose unchanged
                 dden += e6[k] * e6[k];
-                dnum += d * d;
-                e6[k] -= d;
+                dnum += dk * dk;
+                e6[k] -= dk;
             }
-            if (active && lane < 6) ext[((size_t)cand * N + ii) * EXT + lane] = e6[lane];
 #pragma unroll
             for (int a = 0; a < NINTR; a++) in[a] = st->intr_cand[a];
         } else {
 #pragma unroll
             for (int a = 0; a < NINTR; a++) in[a] = st->intr_prev[a];
         }
+        wave_lds_sync();                              // head consumed: the tile may overwrite it
 
         // ---- 2./3. rows -> LDS -> f64 MFMA Gram ----
-        double R[9], dR[27];
-        rodrigues(e6, R, dR);
+        STAMP(2);
+        double R[9], K[9];
+        rodrigues_RK(e6, R, K);
+        STAMP(3);
         const double aspect = st->aspect;
         d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        const float2 *img2 = reinterpret_cast<const float2 *>(img) + (size_t)ii * P;
         for (int c0 = 0; c0 < P; c0 += 64) {
             const int p = c0 + lane;
             const bool valid = p < P;
-            const int pc = valid ? p : P - 1;
-            const double M[3] = {(double)obj[3 * pc], (double)obj[3 * pc + 1], (double)obj[3 * pc + 2]};
-            const float2 uv = img2[pc];             // coalesced 8 B per lane
+            if (c0 > 0) {
+                const int pc = valid ? p : P - 1;
+                uv = img2[pc];
+                m0 = obj[3 * pc]; m1 = obj[3 * pc + 1]; m2 = obj[3 * pc + 2];
+            }
+            const double M[3] = {(double)m0, (double)m1, (double)m2};
             double mu[NCOL], mv[NCOL];
-            point_rows(M, (double)uv.x, (double)uv.y, R, dR, e6 + 3, in, aspect, mu, mv);
-            tile_store_rows(tile, lane, mu, mv, valid);
-            __syncthreads();
-            tile_gram(tile, lane, min(64, P - c0), acc0, acc1);
-            __syncthreads();
+            point_rows_K(M, (double)uv.x, (double)uv.y, R, K, e6 + 3, in, aspect, mu, mv);
+            STAMP(4);
+            tile_store_rows(W, lane, mu, mv, valid);
+            wave_lds_sync();
+            STAMP(5);
+            tile_gram(W, lane, min(64, P - c0), acc0, acc1);
+            wave_lds_sync();                          // operands are in registers: the tile is free
         }
         gram_to_lds(Gs, lane, acc0, acc1);
+        STAMP(6);
     } else {
-        // ---- re-Schur pass: rebuild the C / B / h entries of G from the stored raw blocks ----
+        // ---- re-Schur pass: rows 0..5 of G (raw C, B, h) come back from the stored block ----
+        const double *bp = blk + ((size_t)par * N + ii) * BLK + BLK_G;
+        const double g0 = bp[lane], g1 = lane < 32 ? bp[64 + lane] : 0.0;
 #pragma unroll
         for (int r = 0; r < 4; r++) Gs[lane + 64 * r] = 0.0;
-        __syncthreads();
-        const double *bp = blk + ((size_t)par * N + ii) * BLK;
-        for (int o = lane; o < BLK_RAW; o += 64) {
-            const double v = bp[o];
-            if (o < BLK_B) Gs[TRI6_A[o] * 16 + TRI6_B[o]] = v;
-            else if (o < BLK_H) Gs[((o - BLK_B) % 6) * 16 + 6 + (o - BLK_B) / 6] = v;
-            else Gs[(o - BLK_H) * 16 + COL_E] = v;
-        }
+        wave_lds_sync();
+        Gs[lane] = g0;
+        if (lane < 32) Gs[64 + lane] = g1;
     }
-    __syncthreads();
+    wave_lds_sync();
 
     if (gram_out != nullptr && active) {
 #pragma unroll
         for (int r = 0; r < 4; r++) gram_out[(size_t)ii * 256 + lane + 64 * r] = Gs[lane + 64 * r];
     }
 
-    // ---- 4. damped factor and Schur contribution at lam_next ----
+    // ---- 4. damped factor, U = C_l^-1 [B^T | h] and Y = L^-1 [B^T | h] at lam_next ----
+    STAMP(7);
     double C[21], inv[6];
 #pragma unroll
-    for (int k = 0; k < 21; k++) C[k] = Gs[TRI6_A[k] * 16 + TRI6_B[k]];   // LDS broadcast reads
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = 0; b <= a; b++) C[tri(a, b)] = Gs[a * 16 + b];   // LDS broadcast reads
     damp_diag<6>(C, st->lam_next);
     const bool pd = chol_packed<6>(C, inv);
     {
-        // lane j < 10 owns column j of [B^T | h] and forward-substitutes it: Y_j = L^-1 col_j
+        // lane j < 10 owns column j of [B^T | h]
         const int j = lane < 10 ? lane : 9;
         const int col = j < 9 ? 6 + j : COL_E;
         double y[6];
@@ -170,57 +211,64 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_sweep(const float *__restrict
 #pragma unroll
             for (int k = 0; k < 6; k++) Ys[j * 6 + k] = y[k];
         }
+        bwd_subst<6>(C, inv, y);
+        if (lane < 10) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) Hs[BLK_U + j * 6 + k] = y[k];
+        }
         if (lane == 0) {
 #pragma unroll
-            for (int k = 0; k < 21; k++) Ls[k] = C[k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) Ls[21 + k] = inv[k];
-            Ls[27] = pd ? 1.0 : 0.0;
+            for (int k = 0; k < 6; k++) Hs[BLK_EXT + k] = e6[k];
+            Hs[6] = Hs[7] = 0.0;
+            Hs[BLK_PD] = pd ? 1.0 : 0.0;
+            Hs[69] = Hs[70] = Hs[71] = 0.0;
         }
     }
-    __syncthreads();
+    wave_lds_sync();
 
-    // ---- keep this image's blocks: raw part for re-damping, factor part for back-substitution ----
+    // ---- keep this image's block: head for the next prologue, G rows for re-damping ----
+    STAMP(8);
     if (active) {
         double *bo = blk + ((size_t)cand * N + ii) * BLK;
-        for (int o = lane; o < BLK_USED; o += 64) {
-            double v;
-            if (o < BLK_RAW) {
-                if (mode == MODE_RESCHUR) continue;      // raw blocks unchanged
-                if (o < BLK_B) v = Gs[TRI6_A[o] * 16 + TRI6_B[o]];
-                else if (o < BLK_H) v = Gs[((o - BLK_B) % 6) * 16 + 6 + (o - BLK_B) / 6];
-                else v = Gs[(o - BLK_H) * 16 + COL_E];
-            } else if (o < BLK_Y) {
-                v = (o < BLK_L + 28) ? Ls[o - BLK_L] : 0.0;
-            } else {
-                v = Ys[o - BLK_Y];
-            }
-            bo[o] = v;
+        bo[lane] = Hs[lane];
+        if (lane < 8) bo[64 + lane] = Hs[64 + lane];
+        if (mode != MODE_RESCHUR) {
+            bo[BLK_G + lane] = Gs[lane];
+            if (lane < 32) bo[BLK_G + 64 + lane] = Gs[64 + lane];
         }
     }
 
+    // ---- this image's 112 contributions to the reduced system ----
+    STAMP(9);
     const double err_i = Gs[COL_E * 16 + COL_E];
     const bool finite = (err_i == err_i) && (fabs(err_i) < 1.0e300);
-    for (int o = lane; o < NRED; o += 64) {
-        double v = 0.0;
-        if (o < RED_SC) {                           // A, g straight from G
-            if (mode != MODE_RESCHUR) {
-                if (o < RED_G) v = Gs[(6 + TRI10_A[o]) * 16 + 6 + TRI10_B[o]];
-                else v = Gs[(6 + (o - RED_G)) * 16 + COL_E];
-            }
-        } else if (o < RED_ERR) {                   // SC, sg from Y^T Y
-            int a, b;
-            if (o < RED_SG) { a = TRI10_A[o - RED_SC]; b = TRI10_B[o - RED_SC]; }
-            else { a = o - RED_SG; b = 9; }
+    {
+        // first output o = lane: A (45) | g (9) | SC[0..9]
+        double v;
+        if (lane < RED_G) v = (mode != MODE_RESCHUR) ? Gs[(6 + oa[0]) * 16 + 6 + ob[0]] : 0.0;
+        else if (lane < RED_SC) v = (mode != MODE_RESCHUR) ? Gs[(6 + lane - RED_G) * 16 + COL_E] : 0.0;
+        else {
             double acc = 0.0;
 #pragma unroll
-            for (int k = 0; k < 6; k++) acc += Ys[a * 6 + k] * Ys[b * 6 + k];
+            for (int k = 0; k < 6; k++) acc += Ys[oa[0] * 6 + k] * Ys[ob[0] * 6 + k];
             v = pd ? acc : 0.0;
-        } else if (o == RED_ERR) v = (mode != MODE_RESCHUR) ? err_i : 0.0;
-        else if (o == RED_DNUM) v = dnum;
-        else if (o == RED_DDEN) v = dden;
-        else v = (pd && finite) ? 0.0 : 1.0;
-        red[o] = active ? v : 0.0;
+        }
+        red[lane] = active ? v : 0.0;
+        // second output o = lane + 64: SC[10..44] | sg (9) | err dnum dden bad
+        const int o = lane + 64;
+        if (o < NRED) {
+            if (o < RED_ERR) {
+                const int a = o < RED_SG ? oa[1] : o - RED_SG, b = o < RED_SG ? ob[1] : 9;
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) acc += Ys[a * 6 + k] * Ys[b * 6 + k];
+                v = pd ? acc : 0.0;
+            } else if (o == RED_ERR) v = (mode != MODE_RESCHUR) ? err_i : 0.0;
+            else if (o == RED_DNUM) v = dnum;
+            else if (o == RED_DDEN) v = dden;
+            else v = (pd && finite) ? 0.0 : 1.0;
+            red[o] = active ? v : 0.0;
+        }
     }
     __syncthreads();
     if (tid < NRED) {
@@ -229,7 +277,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_sweep(const float *__restrict
         for (int w = 1; w < WAVES; w++) s += s_red[w * NRED + tid];   // fixed order
         partials[(size_t)blockIdx.x * NRED + tid] = s;
     }
+    STAMP(10);
 }
+
+#ifdef CCAL_STAMPS
+hipError_t debug_read_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32);
+}
+#endif
 
 // ---------------------------------------------------------------------------------------
 // reduce + CvLevMarq state machine + 9x9 Schur solve
@@ -364,7 +419,8 @@ static_assert(sizeof(LmState) % 8 == 0, "LmState is copied as 8-byte words");
 // final state is also written straight into the caller's pinned host mirror (no copy node).
 __global__ __launch_bounds__(SOLVE_THREADS) void k_lm_solve(LmState *st, const double *__restrict__ partials,
                                                              double *red, TraceRec *trace, LmState *host_result,
-                                                             int nblocks, int do_reduce, int do_solve) {
+                                                             unsigned long long *host_progress, int nblocks,
+                                                             int do_reduce, int do_solve) {
     __shared__ double part[SOLVE_SLICES][128];
     __shared__ double rs[NRED];
     __shared__ LmState ls;
@@ -411,17 +467,30 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_lm_solve(LmState *st, const d
         reinterpret_cast<double *>(st)[i] = w;
         if (finished) reinterpret_cast<double *>(host_result)[i] = w;
     }
+    if (host_progress != nullptr) {
+        // progress word for the host's spin-wait: (trials << 32) | done, published after the
+        // state words of every thread have reached host memory
+        if (finished) __threadfence_system();
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(host_progress, ((unsigned long long)(unsigned)ls.trials << 32) | (ls.done ? 1ull : 0ull),
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
 // begin: (re)build the LM state on the device and restore the initial poses
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lm_begin(LmState *st, LmInit init, const double *__restrict__ intr0,
-                                                   const double *__restrict__ ext0, double *__restrict__ ext) {
+                                                   const double *ext0, int ext0_stride, double *blk) {
     const int tid = threadIdx.x;
-    const size_t n = (size_t)init.N_local * EXT;
-    if (ext != ext0)
-        for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n; i += (size_t)gridDim.x * 256) ext[i] = ext0[i];
+    // initial rvec,tvec of image i -> head of its parity-0 block (the source may be that block)
+    const size_t n = (size_t)init.N_local * 8;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t im = i >> 3, k = i & 7;
+        const double v = k < 6 ? ext0[im * ext0_stride + k] : 0.0;
+        blk[im * BLK + BLK_EXT + k] = v;
+    }
     if (blockIdx.x != 0) return;
     __shared__ LmState ls;
     for (int i = tid; i < STATE_WORDS; i += 256) reinterpret_cast<double *>(&ls)[i] = 0.0;
@@ -460,24 +529,25 @@ __global__ __launch_bounds__(256) void k_lm_begin(LmState *st, LmInit init, cons
 int lm_sweep_blocks(int N) { return (N + WAVES - 1) / WAVES; }
 
 hipError_t launch_lm_begin(hipStream_t stream, LmState *st, const LmInit &init, const double *intr0, const double *ext0,
-                           double *ext) {
-    const int blocks = (int)((((size_t)init.N_local * EXT) + 255) / 256);
+                           int ext0_stride, double *blk) {
+    const int blocks = (int)((((size_t)init.N_local * 8) + 255) / 256);
     hipLaunchKernelGGL(k_lm_begin, dim3(blocks < 1 ? 1 : (blocks > 64 ? 64 : blocks)), dim3(256), 0, stream, st, init,
-                       intr0, ext0, ext);
+                       intr0, ext0, ext0_stride, blk);
     return hipGetLastError();
 }
 
-hipError_t launch_lm_sweep(hipStream_t stream, const float *obj, const float *img, double *ext, double *blk,
-                           const LmState *st, double *partials, double *gram_out, int N, int P) {
-    hipLaunchKernelGGL(k_lm_sweep, dim3(lm_sweep_blocks(N)), dim3(WAVES * 64), 0, stream, obj, img, ext, blk, st,
-                       partials, gram_out, N, P);
+hipError_t launch_lm_sweep(hipStream_t stream, const float *obj, const float *img, double *blk, const LmState *st,
+                           double *partials, double *gram_out, int N, int P) {
+    hipLaunchKernelGGL(k_lm_sweep, dim3(lm_sweep_blocks(N)), dim3(WAVES * 64), 0, stream, obj, img, blk, st, partials,
+                       gram_out, N, P);
     return hipGetLastError();
 }
 
 hipError_t launch_lm_solve(hipStream_t stream, LmState *st, const double *partials, double *red, TraceRec *trace,
-                           LmState *host_result, int nblocks, int do_reduce, int do_solve) {
+                           LmState *host_result, unsigned long long *host_progress, int nblocks, int do_reduce,
+                           int do_solve) {
     hipLaunchKernelGGL(k_lm_solve, dim3(1), dim3(SOLVE_THREADS), 0, stream, st, partials, red, trace, host_result,
-                       nblocks, do_reduce, do_solve);
+                       host_progress, nblocks, do_reduce, do_solve);
     return hipGetLastError();
 }
 

@@ -132,6 +132,110 @@ CCAL_HD void point_rows(const double M[3], double u_obs, double v_obs, const dou
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Rotation and its derivative in "left Jacobian" form.  With r = theta n:
+//     R = cos(th) I + (sin(th)/th) [r]x + a r r^T           a = (1 - cos th) / th^2
+//     K = (sin(th)/th) I + a [r]x + b r r^T  (= J_l(r))      b = (th - sin th) / th^3
+// and  d(R M)/d r_j = K[:,j] x (R M)  -- the same derivative as the 3x9 Rodrigues Jacobian of
+// SURVEY.md A.2 contracted with M (checked against it in tests), at a fraction of the
+// wave-uniform arithmetic.  Series below th^2 = 1e-2 avoid cancellation in a and b.
+// ---------------------------------------------------------------------------------------
+CCAL_HD void rodrigues_RK(const double r[3], double R[9], double K[9]) {
+    const double t2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    double sc, c, a, b;   // sc = sin(th)/th
+    if (t2 <= 10.0) {
+        // th <= pi (every rotation): alternating Taylor series in th^2, 18 terms, absolute error
+        // < 1e-16; three independent Horner chains, no sqrt / sincos / divide
+        //   sc = sum (-t2)^k / (2k+1)!   a = sum (-t2)^k / (2k+2)!   b = sum (-t2)^k / (2k+3)!
+        sc = 0.0; a = 0.0; b = 0.0;
+        // 1/(2k+1)!, highest order first; the other two tables follow by division (folded at compile time)
+        const double CS[18] = {1.0 / 1.0333147966386145e40, 1.0 / 8.683317618811886e36, 1.0 / 8.222838654177922e33,
+                               1.0 / 8.841761993739702e30, 1.0 / 1.0888869450418352e28, 1.0 / 1.5511210043330986e25,
+                               1.0 / 2.585201673888498e22, 1.0 / 5.109094217170944e19, 1.0 / 1.21645100408832e17,
+                               1.0 / 3.55687428096e14, 1.0 / 1.307674368e12, 1.0 / 6227020800.0, 1.0 / 39916800.0,
+                               1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0, 1.0};
+#pragma unroll
+        for (int k = 0; k < 18; k++) {
+            const int ord = 17 - k;                       // power of (-t2)
+            const double cs = CS[k];                      // 1/(2 ord + 1)!
+            const double ca = cs / (double)(2 * ord + 2); // 1/(2 ord + 2)!
+            const double cb = ca / (double)(2 * ord + 3); // 1/(2 ord + 3)!
+            sc = sc * (-t2) + cs;
+            a = a * (-t2) + ca;
+            b = b * (-t2) + cb;
+        }
+        c = 1.0 - t2 * a;
+    } else {
+        const double th = sqrt(t2);
+        double sn;
+#if defined(__HIP_DEVICE_COMPILE__)
+        sincos(th, &sn, &c);
+#else
+        sn = sin(th); c = cos(th);
+#endif
+        const double it2 = 1.0 / t2;
+        sc = sn / th;
+        a = (1.0 - c) * it2;
+        b = (1.0 - sc) * it2;
+    }
+    const double xx = r[0] * r[0], yy = r[1] * r[1], zz = r[2] * r[2];
+    const double xy = r[0] * r[1], xz = r[0] * r[2], yz = r[1] * r[2];
+    R[0] = c + a * xx;          R[1] = a * xy - sc * r[2];  R[2] = a * xz + sc * r[1];
+    R[3] = a * xy + sc * r[2];  R[4] = c + a * yy;          R[5] = a * yz - sc * r[0];
+    R[6] = a * xz - sc * r[1];  R[7] = a * yz + sc * r[0];  R[8] = c + a * zz;
+    K[0] = sc + b * xx;         K[1] = b * xy - a * r[2];   K[2] = b * xz + a * r[1];
+    K[3] = b * xy + a * r[2];   K[4] = sc + b * yy;         K[5] = b * yz - a * r[0];
+    K[6] = b * xz - a * r[1];   K[7] = b * yz + a * r[0];   K[8] = sc + b * zz;
+}
+
+// point_rows with the rotation derivative in K form (same columns as point_rows)
+CCAL_HD void point_rows_K(const double M[3], double u_obs, double v_obs, const double R[9],
+                          const double K[9], const double t[3], const double in[NINTR],
+                          double aspect, double mu[NCOL], double mv[NCOL]) {
+    const double fx = in[0], fy = in[1], cx = in[2], cy = in[3];
+    const double k1 = in[4], k2 = in[5], p1 = in[6], p2 = in[7], k3 = in[8];
+    const double Xr = R[0] * M[0] + R[1] * M[1] + R[2] * M[2];
+    const double Yr = R[3] * M[0] + R[4] * M[1] + R[5] * M[2];
+    const double Zr = R[6] * M[0] + R[7] * M[1] + R[8] * M[2];
+    const double X = Xr + t[0], Y = Yr + t[1], Z = Zr + t[2];
+    const double z = (Z != 0.0) ? 1.0 / Z : 1.0;
+    const double x = X * z, y = Y * z;
+    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    const double a1 = 2.0 * x * y, a2 = r2 + 2.0 * x * x, a3 = r2 + 2.0 * y * y;
+    const double cd = 1.0 + k1 * r2 + k2 * r4 + k3 * r6;
+    const double xd = x * cd + p1 * a1 + p2 * a2;
+    const double yd = y * cd + p1 * a3 + p2 * a1;
+    const double dcd_dr2 = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4;
+
+    mu[COL_E] = fx * xd + cx - u_obs;
+    mv[COL_E] = fy * yd + cy - v_obs;
+    if (aspect > 0.0) { mu[6] = 0.0; mu[7] = xd * aspect; }
+    else              { mu[6] = xd;  mu[7] = 0.0; }
+    mv[6] = 0.0; mv[7] = yd;
+    mu[8] = 1.0; mu[9] = 0.0; mv[8] = 0.0; mv[9] = 1.0;
+    mu[10] = fx * x * r2; mu[11] = fx * x * r4; mu[12] = fx * a1; mu[13] = fx * a2; mu[14] = fx * x * r6;
+    mv[10] = fy * y * r2; mv[11] = fy * y * r4; mv[12] = fy * a3; mv[13] = fy * a1; mv[14] = fy * y * r6;
+
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double dX, dY, dZ;
+        if (j < 3) {   // K[:,j] x (R M)
+            const double kx = K[j], ky = K[3 + j], kz = K[6 + j];
+            dX = ky * Zr - kz * Yr;
+            dY = kz * Xr - kx * Zr;
+            dZ = kx * Yr - ky * Xr;
+        } else {
+            dX = (j == 3) ? 1.0 : 0.0; dY = (j == 4) ? 1.0 : 0.0; dZ = (j == 5) ? 1.0 : 0.0;
+        }
+        const double dx = z * (dX - x * dZ), dy = z * (dY - y * dZ);
+        const double dr2 = 2.0 * x * dx + 2.0 * y * dy;
+        const double dcd = dcd_dr2 * dr2;
+        const double da1 = 2.0 * (x * dy + y * dx);
+        mu[j] = fx * (cd * dx + x * dcd + p1 * da1 + p2 * (dr2 + 4.0 * x * dx));
+        mv[j] = fy * (cd * dy + y * dcd + p1 * (dr2 + 4.0 * y * dy) + p2 * da1);
+    }
+}
+
 // Residual only (maps / error metrics use the single-k Julia model separately).
 CCAL_HD void point_residual(const double M[3], double u_obs, double v_obs, const double R[9],
                             const double t[3], const double in[NINTR], double &eu, double &ev) {

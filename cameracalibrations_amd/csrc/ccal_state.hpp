@@ -3,13 +3,12 @@
 // HBM layout of one fit (N = images on this GPU, P = corners per image):
 //   obj      [3,P]      f32   board template (shared by every image)
 //   img      [2,P,N]    f32   observed corners; the only O(N*P) stream: 8 B per corner-residual
-//   ext      [2][N][8]  f64   rvec,tvec (+2 pad) per image, double-buffered: parity p holds the
-//                             last ACCEPTED point ("prev"), 1-p the candidate being evaluated
-//   blk      [2][N][176] f64  per-image normal-equation blocks, same double-buffering:
-//                             raw C (6x6 packed, 21) | B (9x6) | h (6), kept so that a rejected step
-//                             can be re-damped without another sweep, and the damped factor
-//                             L | 1/diag(L) | pd flag | Y = L^-1 [B^T | h] of the lambda the next step
-//                             uses, so that back-substitution needs no second factorisation
+//   ext0     [N][8]     f64   initial rvec,tvec (+2 pad) per image (a solve can be re-run from it)
+//   blk      [2][N][168] f64  per-image state, double-buffered: parity p holds the last ACCEPTED
+//                             point ("prev"), 1-p the candidate being evaluated.  Per image:
+//                             rvec,tvec | U = C_l^-1 [B^T | h] for the lambda the next step uses
+//                             (back-substitution is then one 6x9 mat-vec) | pd flag | rows 0..5 of
+//                             the Gram matrix (raw C, B, h) for re-damping after a rejected step
 //   partials [nblk][112] f64  per-workgroup partial sums of the reduced intrinsic system
 //   red      [112]      f64   the reduced system (what is all-reduced across GPUs)
 //   LmState             the OpenCV CvLevMarq state machine, advanced on device
@@ -29,16 +28,15 @@ constexpr int RED_DNUM = 109;  // sum ||ext_cand - ext_prev||^2
 constexpr int RED_DDEN = 110;  // sum ||ext_prev||^2
 constexpr int RED_BAD = 111;   // images with a non-PD block or non-finite error
 
-constexpr int BLK = 176;       // per-image block stride (doubles)
-constexpr int BLK_C = 0;       // C packed lower 6x6 (raw, undamped)
-constexpr int BLK_B = 21;      // B[a][k], a = intrinsic slot 0..8, k = extrinsic 0..5
-constexpr int BLK_H = 75;      // h[k]
-constexpr int BLK_RAW = 81;    // end of the raw part
-constexpr int BLK_L = 81;      // Cholesky factor of the damped C, packed lower (21)
-constexpr int BLK_INV = 102;   // 1 / diag(L) (6)
-constexpr int BLK_PD = 108;    // 1.0 if the damped block was positive definite
-constexpr int BLK_Y = 112;     // Y[j][k] = (L^-1 col_j)[k], j = 0..8 columns of B^T, j = 9: h  (60)
-constexpr int BLK_USED = 172;
+// per-image block (doubles): everything the next sweep's prologue needs sits in the first 72
+// doubles, so one coalesced 576-B read per parity fetches it
+constexpr int BLK = 168;       // per-image block stride
+constexpr int BLK_EXT = 0;     // rvec, tvec (6) + 2 pad
+constexpr int BLK_U = 8;       // U[j][k] = (C_l^-1 col_j)[k]: j = 0..8 columns of B^T, j = 9: h   (60)
+constexpr int BLK_PD = 68;     // 1.0 if the damped 6x6 block was positive definite (+3 pad)
+constexpr int BLK_HEAD = 72;   // size of the prologue part
+constexpr int BLK_G = 72;      // rows 0..5 of the Gram matrix G (6 x 16): raw C | B^T | h, kept so that a
+                               // rejected step can be re-damped without another sweep
 constexpr int EXT = 8;         // per-image extrinsic stride (doubles)
 
 enum : int { MODE_INIT = 0, MODE_EVAL = 1, MODE_RESCHUR = 2 };

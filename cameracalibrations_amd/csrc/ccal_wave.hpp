@@ -35,22 +35,34 @@ __device__ __forceinline__ void tile_store_rows(double *tile, int lane, const do
     }
 }
 
+// Wave-private LDS hand-off: the DS unit executes one wave's instructions in order, so a
+// ds_write followed by a ds_read of the SAME wave needs no s_barrier; this only stops the
+// compiler from moving LDS accesses of different lanes' addresses across the hand-off.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Accumulate the Gram matrix of the first `npts` corners of the tile.  Each MFMA k-step
 // consumes 4 rows = 2 corners; lane l supplies M[4s + (l>>4)][l&15] as BOTH operands
-// (A = M^T, B = M share one register).  Two accumulators hide the dependent-issue latency.
+// (A = M^T, B = M share one register).  Operands are fetched four k-steps ahead of the MFMAs
+// (all 64 corners' rows are always written, zero when invalid, so rounding the step count up
+// to a multiple of 4 only adds zero rows); two accumulators hide the dependent-issue latency.
 __device__ __forceinline__ void tile_gram(const double *tile, int lane, int npts, d4 &acc0, d4 &acc1) {
     const int rd_off = (lane >> 5) * TILE_LD + ((lane >> 4) & 1) * 16 + (lane & 15);
-    const int nsteps = (npts + 1) >> 1;
-    int s = 0;
-    for (; s + 1 < nsteps; s += 2) {
-        const double a0 = tile[s * 2 * TILE_LD + rd_off];
-        const double a1 = tile[(s + 1) * 2 * TILE_LD + rd_off];
+    const int nsteps = (((npts + 1) >> 1) + 3) & ~3;
+    const double *src = tile + rd_off;
+    double a0 = src[0], a1 = src[2 * TILE_LD], a2 = src[4 * TILE_LD], a3 = src[6 * TILE_LD];
+    for (int s = 0; s < nsteps; s += 4) {
+        const int sn = (s + 4 < nsteps) ? s + 4 : s;          // last group re-reads itself (unused)
+        const double *nx = src + sn * 2 * TILE_LD;
+        const double b0 = nx[0], b1 = nx[2 * TILE_LD], b2 = nx[4 * TILE_LD], b3 = nx[6 * TILE_LD];
         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
-    }
-    if (s < nsteps) {
-        const double a0 = tile[s * 2 * TILE_LD + rd_off];
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc1, 0, 0, 0);
+        a0 = b0; a1 = b1; a2 = b2; a3 = b3;
     }
 }
 
