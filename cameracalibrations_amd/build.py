@@ -12,8 +12,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["ccal_lm.hip", "ccal_init.hip", "ccal_maps.hip", "ccal_api.hip"]
-HEADERS = ["ccal_math.hpp", "ccal_state.hpp", "ccal_wave.hpp", "ccal_kernels.hpp", "../../include/ccal.h"]
+SOURCES = ["ccal_lm.hip", "ccal_init.hip", "ccal_maps.hip", "ccal_comm.hip", "ccal_api.hip"]
+HEADERS = ["ccal_math.hpp", "ccal_state.hpp", "ccal_wave.hpp", "ccal_kernels.hpp", "ccal_comm.hpp",
+           "../../include/ccal.h"]
 LIB = os.path.join(HERE, "libccal_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"]
 
@@ -39,7 +40,7 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/ccal.h"
+#include "ccal_comm.hpp"
 #include "ccal_kernels.hpp"
 #include "ccal_state.hpp"
 
@@ -74,6 +75,7 @@ struct ccal_ctx {
     ccal_allreduce_fn ar_fn = nullptr;
     void *ar_user = nullptr;
     int world = 1, rank = 0;
+    Comm *comm = nullptr;              // native RCCL communicator (ccal_comm_init_rank)
     int64_t n_global = 0;
     int lm_batch = 8;
     // optional per-sweep event timing
@@ -159,6 +161,7 @@ void ccal_destroy(ccal_ctx *c) {
     if (c->g_cont) (void)hipGraphExecDestroy(c->g_cont);
     (void)hipHostFree(c->h_st); (void)hipHostFree(c->h_flags);
     for (auto &e : c->ev) (void)hipEventDestroy(e);
+    delete c->comm;
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -174,12 +177,42 @@ int ccal_set_allreduce(ccal_ctx *c, ccal_allreduce_fn fn, void *user, int32_t wo
     if (!c) return fail(CCAL_E_ARG, "ccal_set_allreduce: ctx == NULL");
     if (world_size < 1 || rank < 0 || rank >= world_size) return fail(CCAL_E_ARG, "ccal_set_allreduce: bad rank/world");
     if (world_size > 1 && (!fn || n_images_global < 1)) return fail(CCAL_E_ARG, "ccal_set_allreduce: hook missing");
+    if (fn && n_images_global < 1) return fail(CCAL_E_ARG, "ccal_set_allreduce: n_images_global missing");
     c->graph_dirty = true;
-    c->ar_fn = world_size > 1 ? fn : nullptr;
+    delete c->comm;
+    c->comm = nullptr;
+    c->ar_fn = fn;                      // a hook with world_size == 1 is honoured (used by tests)
     c->ar_user = user;
     c->world = world_size;
     c->rank = rank;
-    c->n_global = world_size > 1 ? n_images_global : 0;
+    c->n_global = n_images_global > 0 ? n_images_global : 0;
+    return CCAL_OK;
+}
+
+int ccal_comm_unique_id(char id_out[128]) {
+    if (!id_out) return fail(CCAL_E_ARG, "ccal_comm_unique_id: NULL argument");
+    std::string err;
+    if (Comm::unique_id(id_out, err) != 0) return fail(CCAL_E_COMM, err);
+    return CCAL_OK;
+}
+
+int ccal_comm_init_rank(ccal_ctx *c, int32_t world_size, int32_t rank, const char id[128], int64_t n_images_global) {
+    if (!c || !id) return fail(CCAL_E_ARG, "ccal_comm_init_rank: NULL argument");
+    if (world_size < 1 || rank < 0 || rank >= world_size || n_images_global < 1)
+        return fail(CCAL_E_ARG, "ccal_comm_init_rank: bad rank/world/image count");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->comm) c->comm = new Comm();
+    std::string err;
+    if (c->comm->init(world_size, rank, id, err) != 0) {
+        delete c->comm;
+        c->comm = nullptr;
+        return fail(CCAL_E_COMM, err);
+    }
+    c->graph_dirty = true;
+    c->ar_fn = nullptr;
+    c->world = world_size;
+    c->rank = rank;
+    c->n_global = n_images_global;
     return CCAL_OK;
 }
 
@@ -293,8 +326,15 @@ int ccal_set_extrinsics(ccal_ctx *c, const double *rt_host) {
 }
 
 // ---- A4 / A5: closed-form initialisation on the device ---------------------------------
+static bool sharded(const ccal_ctx *c) { return c->ar_fn != nullptr || (c->comm && c->comm->ready()); }
+
 static int run_allreduce(ccal_ctx *c, double *buf, int n) {
-    if (c->world <= 1 || !c->ar_fn) return CCAL_OK;
+    if (c->comm && c->comm->ready()) {
+        std::string err;
+        if (c->comm->all_reduce_sum(buf, n, c->stream, err) != 0) return fail(CCAL_E_COMM, err);
+        return CCAL_OK;
+    }
+    if (!c->ar_fn) return CCAL_OK;
     const int rc = c->ar_fn(c->ar_user, buf, n, (void *)c->stream);
     if (rc != 0) return fail(CCAL_E_COMM, "all-reduce hook returned " + std::to_string(rc));
     return CCAL_OK;
@@ -309,7 +349,7 @@ static LmInit make_init(const ccal_ctx *c) {
     in.P = c->P;
     in.N_local = c->N;
     in.nblocks = lm_sweep_blocks(c->N);
-    in.N_global = c->world > 1 ? c->n_global : c->N;
+    in.N_global = (sharded(c) && c->n_global > 0) ? c->n_global : c->N;
     // parameter mask from the flag word
     const uint32_t f = c->flags;
     for (int a = 0; a < 9; a++) in.mask[a] = 1;
@@ -405,7 +445,7 @@ static int enqueue_trial(ccal_ctx *c, hipStream_t stream) {
     HIPCHK(launch_lm_sweep(stream, c->d_obj, c->d_img, c->d_blk, c->d_st, c->d_partials, nullptr, c->N, c->P));
     if (timed) HIPCHK(hipEventRecord(c->ev[2 * c->ev_used++ + 1], stream));
     const int nb = lm_sweep_blocks(c->N);
-    if (c->world > 1 && c->ar_fn) {
+    if (sharded(c)) {
         HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nullptr, nullptr, nb, 1, 0));
         const int rc = run_allreduce(c, c->d_red, NRED);
         if (rc) return rc;
@@ -449,7 +489,7 @@ int ccal_lm_run(ccal_ctx *c) {
     c->ev_used = 0;
     c->h_st->done = 0;
     *progress_word(c) = 0ull;
-    const bool graphed = c->use_graph && !c->time_sweeps && !(c->world > 1 && c->ar_fn);
+    const bool graphed = c->use_graph && !c->time_sweeps && !sharded(c);
     if (graphed && c->graph_dirty) {
         HIPCHK(hipStreamSynchronize(c->stream));
         int rc = capture_graph(c, true, &c->g_first);

@@ -17,7 +17,7 @@
 //                lane advances the CvLevMarq state machine: accept / reject, lambda
 //                schedule, stop rule, and the 9x9 damped Schur system for the next step.
 //
-// A rejected step costs one extra "re-Schur" pass over the stored blocks (no projection).
+// A rejected step costs one extra sweep of the accepted point with the larger lambda.
 // Multi-GPU: the 112-double reduced system is all-reduced between the reduce and solve
 // halves of k_lm_solve (host hook), every rank then advances the same state.
 #include <hip/hip_runtime.h>
@@ -116,73 +116,62 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_sweep(const float *__restrict
 #pragma unroll
     for (int k = 0; k < 6; k++) e6[k] = Hs[BLK_EXT + k];    // LDS broadcast reads
     double dnum = 0.0, dden = 0.0;
-
-    if (mode != MODE_RESCHUR) {
-        double in[NINTR];
-        if (mode == MODE_EVAL) {
-            // delta_i = C_l^-1 (h - B^T delta_int) = u_h - U_B delta_int, U kept by the last sweep
-            double d[6];
+    double in[NINTR];
+    if (mode == MODE_EVAL) {
+        // delta_i = C_l^-1 (h - B^T delta_int) = u_h - U_B delta_int, U kept by the last sweep
+        double d[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) d[k] = Hs[BLK_U + 54 + k];
+        for (int k = 0; k < 6; k++) d[k] = Hs[BLK_U + 54 + k];
 #pragma unroll
-            for (int a = 0; a < NINTR; a++) {
-                const double da = st->dint[a];
+        for (int a = 0; a < NINTR; a++) {
+            const double da = st->dint[a];
 #pragma unroll
-                for (int k = 0; k < 6; k++) d[k] -= Hs[BLK_U + a * 6 + k] * da;
-            }
-            const bool ok = Hs[BLK_PD] != 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                const double dk = ok ? d[k] : 0.0;    // degenerate view: leave its pose unchanged
-                dden += e6[k] * e6[k];
-                dnum += dk * dk;
-                e6[k] -= dk;
-            }
-#pragma unroll
-            for (int a = 0; a < NINTR; a++) in[a] = st->intr_cand[a];
-        } else {
-#pragma unroll
-            for (int a = 0; a < NINTR; a++) in[a] = st->intr_prev[a];
+            for (int k = 0; k < 6; k++) d[k] -= Hs[BLK_U + a * 6 + k] * da;
         }
-        wave_lds_sync();                              // head consumed: the tile may overwrite it
-
-        // ---- 2./3. rows -> LDS -> f64 MFMA Gram ----
-        STAMP(2);
-        double R[9], K[9];
-        rodrigues_RK(e6, R, K);
-        STAMP(3);
-        const double aspect = st->aspect;
-        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        for (int c0 = 0; c0 < P; c0 += 64) {
-            const int p = c0 + lane;
-            const bool valid = p < P;
-            if (c0 > 0) {
-                const int pc = valid ? p : P - 1;
-                uv = img2[pc];
-                m0 = obj[3 * pc]; m1 = obj[3 * pc + 1]; m2 = obj[3 * pc + 2];
-            }
-            const double M[3] = {(double)m0, (double)m1, (double)m2};
-            double mu[NCOL], mv[NCOL];
-            point_rows_K(M, (double)uv.x, (double)uv.y, R, K, e6 + 3, in, aspect, mu, mv);
-            STAMP(4);
-            tile_store_rows(W, lane, mu, mv, valid);
-            wave_lds_sync();
-            STAMP(5);
-            tile_gram(W, lane, min(64, P - c0), acc0, acc1);
-            wave_lds_sync();                          // operands are in registers: the tile is free
+        const bool ok = Hs[BLK_PD] != 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const double dk = ok ? d[k] : 0.0;    // degenerate view: leave its pose unchanged
+            dden += e6[k] * e6[k];
+            dnum += dk * dk;
+            e6[k] -= dk;
         }
-        gram_to_lds(Gs, lane, acc0, acc1);
-        STAMP(6);
+#pragma unroll
+        for (int a = 0; a < NINTR; a++) in[a] = st->intr_cand[a];
     } else {
-        // ---- re-Schur pass: rows 0..5 of G (raw C, B, h) come back from the stored block ----
-        const double *bp = blk + ((size_t)par * N + ii) * BLK + BLK_G;
-        const double g0 = bp[lane], g1 = lane < 32 ? bp[64 + lane] : 0.0;
+        // MODE_INIT / MODE_RESCHUR: (re-)evaluate the accepted point itself
 #pragma unroll
-        for (int r = 0; r < 4; r++) Gs[lane + 64 * r] = 0.0;
-        wave_lds_sync();
-        Gs[lane] = g0;
-        if (lane < 32) Gs[64 + lane] = g1;
+        for (int a = 0; a < NINTR; a++) in[a] = st->intr_prev[a];
     }
+    wave_lds_sync();                              // head consumed: the tile may overwrite it
+
+    // ---- 2./3. rows -> LDS -> f64 MFMA Gram ----
+    STAMP(2);
+    double R[9], K[9];
+    rodrigues_RK(e6, R, K);
+    STAMP(3);
+    const double aspect = st->aspect;
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    for (int c0 = 0; c0 < P; c0 += 64) {
+        const int p = c0 + lane;
+        const bool valid = p < P;
+        if (c0 > 0) {
+            const int pc = valid ? p : P - 1;
+            uv = img2[pc];
+            m0 = obj[3 * pc]; m1 = obj[3 * pc + 1]; m2 = obj[3 * pc + 2];
+        }
+        const double M[3] = {(double)m0, (double)m1, (double)m2};
+        double mu[NCOL], mv[NCOL];
+        point_rows_K(M, (double)uv.x, (double)uv.y, R, K, e6 + 3, in, aspect, mu, mv);
+        STAMP(4);
+        tile_store_rows(W, lane, mu, mv, valid);
+        wave_lds_sync();
+        STAMP(5);
+        tile_gram(W, lane, min(64, P - c0), acc0, acc1);
+        wave_lds_sync();                          // operands are in registers: the tile is free
+    }
+    gram_to_lds(Gs, lane, acc0, acc1);
+    STAMP(6);
     wave_lds_sync();
 
     if (gram_out != nullptr && active) {
@@ -226,16 +215,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_sweep(const float *__restrict
     }
     wave_lds_sync();
 
-    // ---- keep this image's block: head for the next prologue, G rows for re-damping ----
+    // ---- keep this image's block for the next sweep's prologue ----
     STAMP(8);
     if (active) {
         double *bo = blk + ((size_t)cand * N + ii) * BLK;
         bo[lane] = Hs[lane];
         if (lane < 8) bo[64 + lane] = Hs[64 + lane];
-        if (mode != MODE_RESCHUR) {
-            bo[BLK_G + lane] = Gs[lane];
-            if (lane < 32) bo[BLK_G + 64 + lane] = Gs[64 + lane];
-        }
     }
 
     // ---- this image's 112 contributions to the reduced system ----
@@ -245,8 +230,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_sweep(const float *__restrict
     {
         // first output o = lane: A (45) | g (9) | SC[0..9]
         double v;
-        if (lane < RED_G) v = (mode != MODE_RESCHUR) ? Gs[(6 + oa[0]) * 16 + 6 + ob[0]] : 0.0;
-        else if (lane < RED_SC) v = (mode != MODE_RESCHUR) ? Gs[(6 + lane - RED_G) * 16 + COL_E] : 0.0;
+        if (lane < RED_G) v = Gs[(6 + oa[0]) * 16 + 6 + ob[0]];
+        else if (lane < RED_SC) v = Gs[(6 + lane - RED_G) * 16 + COL_E];
         else {
             double acc = 0.0;
 #pragma unroll
@@ -263,7 +248,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_sweep(const float *__restrict
 #pragma unroll
                 for (int k = 0; k < 6; k++) acc += Ys[a * 6 + k] * Ys[b * 6 + k];
                 v = pd ? acc : 0.0;
-            } else if (o == RED_ERR) v = (mode != MODE_RESCHUR) ? err_i : 0.0;
+            } else if (o == RED_ERR) v = err_i;
             else if (o == RED_DNUM) v = dnum;
             else if (o == RED_DDEN) v = dden;
             else v = (pd && finite) ? 0.0 : 1.0;

@@ -4,11 +4,10 @@
 //   obj      [3,P]      f32   board template (shared by every image)
 //   img      [2,P,N]    f32   observed corners; the only O(N*P) stream: 8 B per corner-residual
 //   ext0     [N][8]     f64   initial rvec,tvec (+2 pad) per image (a solve can be re-run from it)
-//   blk      [2][N][168] f64  per-image state, double-buffered: parity p holds the last ACCEPTED
-//                             point ("prev"), 1-p the candidate being evaluated.  Per image:
+//   blk      [2][N][72] f64   per-image state, double-buffered: parity p holds the last ACCEPTED
+//                             point ("prev"), 1-p the candidate being evaluated.  Per image (576 B):
 //                             rvec,tvec | U = C_l^-1 [B^T | h] for the lambda the next step uses
-//                             (back-substitution is then one 6x9 mat-vec) | pd flag | rows 0..5 of
-//                             the Gram matrix (raw C, B, h) for re-damping after a rejected step
+//                             (back-substitution is then one 6x9 mat-vec) | pd flag
 //   partials [nblk][112] f64  per-workgroup partial sums of the reduced intrinsic system
 //   red      [112]      f64   the reduced system (what is all-reduced across GPUs)
 //   LmState             the OpenCV CvLevMarq state machine, advanced on device
@@ -30,16 +29,16 @@ constexpr int RED_BAD = 111;   // images with a non-PD block or non-finite error
 
 // per-image block (doubles): everything the next sweep's prologue needs sits in the first 72
 // doubles, so one coalesced 576-B read per parity fetches it
-constexpr int BLK = 168;       // per-image block stride
+constexpr int BLK = 72;        // per-image block stride
 constexpr int BLK_EXT = 0;     // rvec, tvec (6) + 2 pad
 constexpr int BLK_U = 8;       // U[j][k] = (C_l^-1 col_j)[k]: j = 0..8 columns of B^T, j = 9: h   (60)
 constexpr int BLK_PD = 68;     // 1.0 if the damped 6x6 block was positive definite (+3 pad)
-constexpr int BLK_HEAD = 72;   // size of the prologue part
-constexpr int BLK_G = 72;      // rows 0..5 of the Gram matrix G (6 x 16): raw C | B^T | h, kept so that a
-                               // rejected step can be re-damped without another sweep
+// A rejected step is re-damped by sweeping the accepted point again with the larger lambda
+// (MODE_RESCHUR): rejections are rare, and not keeping the raw 6x16 Gram rows per image
+// removes 768 B of writes per image from every sweep.
 constexpr int EXT = 8;         // per-image extrinsic stride (doubles)
 
-enum : int { MODE_INIT = 0, MODE_EVAL = 1, MODE_RESCHUR = 2 };
+enum : int { MODE_INIT = 0, MODE_EVAL = 1, MODE_RESCHUR = 2 };   // RESCHUR: re-sweep the accepted point, new lambda
 constexpr int MAX_KINDS = 64;
 
 struct LmState {

@@ -51,3 +51,54 @@ def host_allreduce_sum(arr, group=None):
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     arr[...] = t.numpy()
     return arr
+
+
+def broadcast_id_via_torch(group=None):
+    """-> broadcast_bytes callable for Solver.init_rccl: ships rank 0's 128-byte RCCL id."""
+    import torch
+    import torch.distributed as dist
+
+    def bcast(b):
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if b is not None:
+            t.copy_(torch.frombuffer(bytearray(b), dtype=torch.uint8))
+        dist.broadcast(t, src=0, group=group)
+        return bytes(t.cpu().numpy().tobytes())
+    return bcast
+
+
+def reduced_system_from_gram(G, lam, mask=None):
+    """numpy mirror of one image's contribution to the 112-double reduced system of the device
+    kernels: A, g, SC = B C_l^-1 B^T, sg = B C_l^-1 h, err.  Used by the CPU
+    tests of the sharding logic; G is the 16x16 Gram [Je|Ji|e]^T[Je|Ji|e]."""
+    C = G[:6, :6].copy()
+    C[np.diag_indices(6)] *= 1.0 + lam
+    B = G[6:15, :6]
+    h = G[:6, 15]
+    CiBt = np.linalg.solve(C, B.T)
+    Cih = np.linalg.solve(C, h)
+    return dict(A=G[6:15, 6:15].copy(), g=G[6:15, 15].copy(), SC=B @ CiBt, sg=B @ Cih, err=float(G[15, 15]))
+
+
+def pack_reduced(parts):
+    """sum of per-image contributions -> flat vector (what is all-reduced)."""
+    A = sum(p["A"] for p in parts)
+    g = sum(p["g"] for p in parts)
+    SC = sum(p["SC"] for p in parts)
+    sg = sum(p["sg"] for p in parts)
+    err = sum(p["err"] for p in parts)
+    return np.concatenate([A.ravel(), g, SC.ravel(), sg, [err]])
+
+
+def solve_reduced(vec, lam, mask):
+    """damped Schur system of the device's k_lm_solve: -> delta_int (9), err."""
+    A, g = vec[:81].reshape(9, 9), vec[81:90]
+    SC, sg, err = vec[90:171].reshape(9, 9), vec[171:180], vec[180]
+    S = A - SC
+    S[np.diag_indices(9)] = np.diag(A) * (1.0 + lam) - np.diag(SC)
+    rhs = g - sg
+    free = np.array(mask, dtype=bool) & (np.diag(A) > 0)
+    d = np.zeros(9)
+    d[free] = np.linalg.solve(S[np.ix_(free, free)], rhs[free])
+    return d, err

@@ -59,6 +59,16 @@ class Solver:
         self._keep.append(cb)
         F.check(F.lib().ccal_set_allreduce(self._h, cb, None, int(world_size), int(rank), int(n_images_global)))
 
+    def init_rccl(self, world_size, rank, n_images_global, broadcast_bytes):
+        """Native RCCL all-reduce inside the library.  `broadcast_bytes(b: bytes|None) -> bytes`
+        ships rank 0's 128-byte unique id to every rank (e.g. through torch.distributed)."""
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            F.check(F.lib().ccal_comm_unique_id(buf))
+        ident = broadcast_bytes(buf.raw if rank == 0 else None)
+        assert len(ident) == 128
+        F.check(F.lib().ccal_comm_init_rank(self._h, int(world_size), int(rank), ident, int(n_images_global)))
+
     def set_problem(self, obj, n_images, image_size, aspect=1.0, flags=0, max_iter=30, eps=1e-3):
         """obj (P,3); image_size = (width, height) as OpenCV sees it (src/detect_fit.jl:32)."""
         obj, op = F.f32(obj)

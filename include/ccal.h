@@ -70,8 +70,8 @@ typedef struct ccal_stats {
     double t_init_extr_s;  /* A5: per-view pose initialisation */
     double t_lm_s;         /* A6-A9: global LM loop */
     int32_t iters;         /* accepted LM iterations (OpenCV `iters`) */
-    int32_t sweeps;        /* residual+Jacobian sweeps over all corners */
-    int32_t reschur;       /* extra damping-only passes after rejected steps */
+    int32_t sweeps;        /* residual+Jacobian sweeps over all corners at new candidate points (+ the initial one) */
+    int32_t reschur;       /* further full sweeps that re-damp the accepted point after a rejected step */
     int32_t rejected;      /* rejected trial steps */
     int32_t lambda_lg10;   /* final log10(lambda) */
     int32_t n_bad;         /* images whose 6x6 block was not positive definite in the last sweep */
@@ -108,6 +108,14 @@ int  ccal_set_stream(ccal_ctx *ctx, void *hip_stream);
 typedef int (*ccal_allreduce_fn)(void *user, void *device_buf, int32_t n, void *hip_stream);
 int  ccal_set_allreduce(ccal_ctx *ctx, ccal_allreduce_fn fn, void *user, int32_t world_size,
                         int32_t rank, int64_t n_images_global);
+
+/* Native variant: the library calls RCCL itself (ncclAllReduce on the launch stream; RCCL is
+ * resolved at run time).  Rank 0 obtains an id with ccal_comm_unique_id and ships the 128 bytes to
+ * the other ranks by any means (the Python mirror broadcasts it through torch.distributed);
+ * every rank then calls ccal_comm_init_rank.  Replaces any hook set before. */
+int  ccal_comm_unique_id(char id_out[128]);
+int  ccal_comm_init_rank(ccal_ctx *ctx, int32_t world_size, int32_t rank, const char id[128],
+                         int64_t n_images_global);
 
 /* ---- problem ------------------------------------------------------------------------ */
 /* Replaces the marshalling of fit_model (src/detect_fit.jl:30-45): template, image size

@@ -267,3 +267,38 @@ def test_edge_cases():
     assert abs(m.frow - ro["intr"][0]) < 1e-6 * ro["intr"][0] and m.frow == m.fcol
     assert abs(m.k - ro["intr"][4]) < 1e-6
     assert np.abs(m.Rs[0] - ro["rvecs"][0]).max() < 1e-6
+
+
+def test_allreduce_paths_world1():
+    """The multi-GPU code path (reduce kernel -> all-reduce -> solve kernel, no graph) with one
+    rank: (a) torch.distributed hook (nccl == RCCL), (b) the library's own RCCL communicator.
+    Both must reproduce the graph path bit for bit."""
+    import torch
+    import torch.distributed as dist
+    from cameracalibrations_amd.distributed import TorchAllReduce, broadcast_id_via_torch
+    wl = syn.named_workload("C2", n_images=37)
+    with _solver(wl, REF) as s:
+        _, base = s.calibrate()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        hook = TorchAllReduce()
+        with Solver(0, stream=torch.cuda.current_stream().cuda_stream) as s:
+            s.set_problem(wl.obj, wl.n_images, wl.image_size, aspect=wl.aspect, flags=wl.flags)
+            s.set_image_points(torch.from_numpy(wl.img).cuda())
+            s.set_allreduce(hook, 1, 0, wl.n_images)
+            _, r1 = s.calibrate()
+        assert hook.calls >= r1["sweeps"] + 1            # focal least squares + one per LM trial
+        with Solver(0, stream=torch.cuda.current_stream().cuda_stream) as s:
+            s.set_problem(wl.obj, wl.n_images, wl.image_size, aspect=wl.aspect, flags=wl.flags)
+            s.set_image_points(wl.img)
+            s.init_rccl(1, 0, wl.n_images, broadcast_id_via_torch())
+            _, r2 = s.calibrate()
+    finally:
+        dist.destroy_process_group()
+    for r in (r1, r2):
+        assert r["iters"] == base["iters"] and r["rms"] == base["rms"]
+        for k in ("intr", "rvecs", "tvecs"):
+            assert np.array_equal(r[k], base[k]), k
