@@ -1,0 +1,94 @@
+# CameraCalibrationsAMD.jl -- thin `ccall` binding of libccal_hip.so (include/ccal.h).
+#
+# UNTESTED IN THIS REPOSITORY: the build image has no Julia.  The Python mirror
+# (cameracalibrations_amd/solver.py, tested on MI355X) makes exactly the same calls with the
+# same array layouts; keep the two in step.
+#
+# Drop-in for the reference's FFI seam: define `fit_model` with the signature of
+# reference src/detect_fit.jl:27 and return the NamedTuple of :60.  In CameraCalibrations.jl
+# replace the body of `fit_model` by `CameraCalibrationsAMD.fit_model(args...)`, or
+#     @eval CameraCalibrations fit_model(args...) = CameraCalibrationsAMD.fit_model(args...)
+module CameraCalibrationsAMD
+
+using StaticArrays
+
+const LIB = get(ENV, "CCAL_LIB", joinpath(@__DIR__, "..", "cameracalibrations_amd", "libccal_hip.so"))
+
+# OpenCV flag bits used by the reference (src/detect_fit.jl:40)
+const ZERO_TANGENT_DIST = 0x00000008
+const FIX_ASPECT_RATIO  = 0x00000002
+const FIX_K1 = 0x00000020
+const FIX_K2 = 0x00000040
+const FIX_K3 = 0x00000080
+const CRITERIA = (30, 0.001)          # src/CameraCalibrations.jl:16
+
+struct CcalError <: Exception
+    code::Int32
+    msg::String
+end
+
+function check(rc::Int32)
+    rc < 0 && throw(CcalError(rc, unsafe_string(ccall((:ccal_last_error, LIB), Cstring, ()))))
+    return rc
+end
+
+"""
+    fit_model(sz, objpoints, imgpointss, n_corners, with_distortion, aspect)
+
+Same contract as the reference wrapper of `OpenCV.calibrateCamera`: `objpoints` is the
+n1 x n2 x 1 template of XYZ, `imgpointss` a vector of n1 x n2 matrices of RowCol, `sz` the
+size of the Julia image (== OpenCV (width, height), src/detect_fit.jl:32).
+"""
+function fit_model(sz, objpoints, imgpointss, n_corners, with_distortion, aspect; device = 0)
+    P = prod(n_corners)
+    N = length(imgpointss)
+    obj = Float32.(reshape(reinterpret(reshape, eltype(eltype(objpoints)), vec(objpoints)), 3, P))   # [3,P]
+    img = Array{Float32}(undef, 2, P, N)                                                         # [2,P,N]
+    for (i, m) in enumerate(imgpointss), (p, rc) in enumerate(vec(m))
+        img[1, p, i] = rc[1]; img[2, p, i] = rc[2]
+    end
+    flags = ZERO_TANGENT_DIST | FIX_K3 | FIX_K2 | (with_distortion ? 0x0 : FIX_K1) | FIX_ASPECT_RATIO
+    K4 = zeros(Float64, 4); dist = zeros(Float64, 5)
+    rvecs = zeros(Float64, 3, N); tvecs = zeros(Float64, 3, N)
+    rms = Ref{Float64}(0); iters = Ref{Int32}(0)
+    check(ccall((:ccal_calibrate, LIB), Int32,
+                (Ptr{Float32}, Ptr{Float32}, Int32, Int32, Int32, Int32, Float64, UInt32, Int32, Float64, Int32,
+                 Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Int32}, Ptr{Cvoid}),
+                obj, img, P, N, sz[1], sz[2], Float64(aspect), flags, CRITERIA[1], CRITERIA[2], device,
+                K4, dist, rvecs, tvecs, rms, iters, C_NULL))
+    k = dist[1]
+    Rs = [rvecs[:, i] for i in 1:N]
+    ts = [tvecs[:, i] for i in 1:N]
+    frow, fcol, crow, ccol = K4
+    return (; k, Rs, ts, frow, fcol, crow, ccol)
+end
+
+# Batched point maps (src/meta.jl:82,88): xyz [3,M] <-> rowcol [2,M] for one image's extrinsics.
+mutable struct Context
+    h::Ptr{Cvoid}
+    function Context(device = 0)
+        r = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:ccal_create, LIB), Int32, (Int32, Ref{Ptr{Cvoid}}), device, r))
+        c = new(r[])
+        finalizer(x -> ccall((:ccal_destroy, LIB), Cvoid, (Ptr{Cvoid},), x.h), c)
+        return c
+    end
+end
+
+function project(c::Context, xyz::Matrix{Float64}, f, cc, k, rvec, tvec, checker_size)
+    M = size(xyz, 2); out = zeros(Float64, 2, M)
+    check(ccall((:ccal_project, LIB), Int32,
+                (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}),
+                c.h, xyz, M, Float64[f...], Float64[cc...], Float64(k), Float64[rvec...], Float64[tvec...], Float64(checker_size), out))
+    return out
+end
+
+function unproject(c::Context, rowcol::Matrix{Float64}, f, cc, k, rvec, tvec, checker_size)
+    M = size(rowcol, 2); out = zeros(Float64, 3, M)
+    check(ccall((:ccal_unproject, LIB), Int32,
+                (Ptr{Cvoid}, Ptr{Float64}, Int32, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}),
+                c.h, rowcol, M, Float64[f...], Float64[cc...], Float64(k), Float64[rvec...], Float64[tvec...], Float64(checker_size), out))
+    return out
+end
+
+end # module
