@@ -8,7 +8,7 @@ Workload (config.workload): BASELINE.json configs[2] -- synthetic pinhole + k1,k
 1000 images x 9x6 corners per GPU (SURVEY.md 8d recipe, cameracalibrations_amd/synthetic.py),
 observed corners resident in HBM before the timed region.  With N GPUs every rank holds its
 own 1000-image shard of ONE joint fit (shared intrinsics): weak scaling, one RCCL all-reduce of
-the 112-double reduced system per LM trial.
+the 68-double reduced system per LM trial.
 
 One step = one complete global LM solve from the closed-form initial
 values (rows A4/A5 run once on the device before timing and are reported separately, as

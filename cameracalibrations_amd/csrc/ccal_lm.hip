@@ -12,13 +12,13 @@
 //                  3. rows -> LDS (padded, conflict-free) -> v_mfma_f64_16x16x4_f64:
 //                     G = [Je|Ji|e]^T [Je|Ji|e]  (16x16; holds JtJ blocks, Jt e and ||e||^2)
 //                  4. damp + Cholesky of the 6x6 extrinsic block, Y = L^-1 [B^T | h], Schur
-//                     contribution Y^T Y, workgroup partial sums -> partials[block][112]
+//                     contribution Y^T Y, workgroup partial sums -> partials[block][68]
 //   k_lm_solve   one workgroup: fixed-order sum of the partials (deterministic), then one
 //                lane advances the CvLevMarq state machine: accept / reject, lambda
 //                schedule, stop rule, and the 9x9 damped Schur system for the next step.
 //
 // A rejected step costs one extra sweep of the accepted point with the larger lambda.
-// Multi-GPU: the 112-double reduced system is all-reduced between the reduce and solve
+// Multi-GPU: the 68-double reduced system is all-reduced between the reduce and solve
 // halves of k_lm_solve (host hook), every rank then advances the same state.
 #include <hip/hip_runtime.h>
 
@@ -45,8 +45,19 @@ __device__ unsigned long long g_stamps[32];
             __builtin_amdgcn_sched_barrier(0);                                                \
         }                                                                                     \
     } while (0)
+#define STAMP2(i)                                                                             \
+    do {                                                                                      \
+        if (threadIdx.x == 0) {                                                               \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            unsigned long long t_;                                                            \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            g_stamps[16 + (i)] = t_;                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+        }                                                                                     \
+    } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMP2(i) do { } while (0)
 #endif
 
 // packed-lower decode o -> (a, b), a >= b, for o < 55 (no memory table: arithmetic in the
@@ -94,9 +105,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_sweep(const float *__restrict
     const int pc0 = lane < P ? lane : P - 1;
     float2 uv = img2[pc0];                      // coalesced 8 B per lane
     float m0 = obj[3 * pc0], m1 = obj[3 * pc0 + 1], m2 = obj[3 * pc0 + 2];
-    int oa[2], ob[2];                           // (a, b) of the packed outputs this lane assembles
-    tri_decode(lane < 45 ? lane : (lane >= 54 ? lane - 54 : 0), oa[0], ob[0]);
-    tri_decode(lane + 64 < RED_SG ? lane + 64 - RED_SC : 0, oa[1], ob[1]);
+    int oa, ob;                                 // (a, b) of the packed S0 entry this lane assembles
+    tri_decode(lane < 45 ? lane : 0, oa, ob);
 
     if (st->done) return;
     STAMP(1);
@@ -223,36 +233,35 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_sweep(const float *__restrict
         if (lane < 8) bo[64 + lane] = Hs[64 + lane];
     }
 
-    // ---- this image's 112 contributions to the reduced system ----
+    // ---- this image's contributions to the reduced system: S0 | dA | gs | err dnum dden bad ----
     STAMP(9);
     const double err_i = Gs[COL_E * 16 + COL_E];
     const bool finite = (err_i == err_i) && (fabs(err_i) < 1.0e300);
     {
-        // first output o = lane: A (45) | g (9) | SC[0..9]
         double v;
-        if (lane < RED_G) v = Gs[(6 + oa[0]) * 16 + 6 + ob[0]];
-        else if (lane < RED_SC) v = Gs[(6 + lane - RED_G) * 16 + COL_E];
-        else {
-            double acc = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) acc += Ys[oa[0] * 6 + k] * Ys[ob[0] * 6 + k];
-            v = pd ? acc : 0.0;
-        }
-        red[lane] = active ? v : 0.0;
-        // second output o = lane + 64: SC[10..44] | sg (9) | err dnum dden bad
-        const int o = lane + 64;
-        if (o < NRED) {
-            if (o < RED_ERR) {
-                const int a = o < RED_SG ? oa[1] : o - RED_SG, b = o < RED_SG ? ob[1] : 9;
+        if (lane < RED_GS) {
+            // lanes 0..44: A(a,b) - Y_a . Y_b;  45..53: A(a,a)
+            const int a = lane < RED_DA ? oa : lane - RED_DA, b = lane < RED_DA ? ob : lane - RED_DA;
+            v = Gs[(6 + a) * 16 + 6 + b];
+            if (lane < RED_DA) {
                 double acc = 0.0;
 #pragma unroll
                 for (int k = 0; k < 6; k++) acc += Ys[a * 6 + k] * Ys[b * 6 + k];
-                v = pd ? acc : 0.0;
-            } else if (o == RED_ERR) v = err_i;
-            else if (o == RED_DNUM) v = dnum;
-            else if (o == RED_DDEN) v = dden;
-            else v = (pd && finite) ? 0.0 : 1.0;
-            red[o] = active ? v : 0.0;
+                v -= pd ? acc : 0.0;
+            }
+        } else if (lane < RED_ERR) {
+            const int a = lane - RED_GS;                  // g(a) - Y_a . Y_h
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) acc += Ys[a * 6 + k] * Ys[54 + k];
+            v = Gs[(6 + a) * 16 + COL_E] - (pd ? acc : 0.0);
+        } else {
+            v = err_i;                                    // lane 63
+        }
+        red[lane] = active ? v : 0.0;
+        if (lane < 4) {
+            const double w = lane == 0 ? dnum : (lane == 1 ? dden : (lane == 2 ? ((pd && finite) ? 0.0 : 1.0) : 0.0));
+            red[64 + lane] = active ? w : 0.0;
         }
     }
     __syncthreads();
@@ -295,14 +304,12 @@ __device__ void lm_advance(LmState *st, const double *rs, TraceRec *trace) {
         st->sweeps++;
         st->prev_err = err;
         st->n_bad = (int)rs[RED_BAD];
-        for (int k = 0; k < 45; k++) st->A_prev[k] = rs[RED_A + k];
-        for (int k = 0; k < 9; k++) st->g_prev[k] = rs[RED_G + k];
         lm_trace(st, trace, err, -1.0, 2);
         if (!(fabs(err) < 1.0e300)) { st->status = -4; st->done = 1; return; }
     } else if (mode == MODE_EVAL) {
         st->sweeps++;
         if (err > st->prev_err && ++st->lambda_lg10 <= 16) {
-            // rejected: same blocks, larger lambda
+            // rejected: sweep the accepted point again with the larger lambda
             st->rejected++;
             st->mode = MODE_RESCHUR;
             st->lg_partials = st->lambda_lg10;
@@ -324,8 +331,6 @@ __device__ void lm_advance(LmState *st, const double *rs, TraceRec *trace) {
         st->parity ^= 1;
         st->prev_err = err;
         st->n_bad = (int)rs[RED_BAD];
-        for (int k = 0; k < 45; k++) st->A_prev[k] = rs[RED_A + k];
-        for (int k = 0; k < 9; k++) st->g_prev[k] = rs[RED_G + k];
         lm_trace(st, trace, err, rel, 1);
         if (!(fabs(err) < 1.0e300)) { st->status = -4; st->done = 1; return; }
         if (st->iters >= st->max_iter || rel < st->eps) {
@@ -340,28 +345,25 @@ __device__ void lm_advance(LmState *st, const double *rs, TraceRec *trace) {
             return;
         }
     } else {
-        st->reschur++;
+        st->reschur++;                              // fresh system of the accepted point at the new lambda
     }
 
-    // ---- step(): damped Schur system  S = A_l - SC,  rhs = g - sg   ----
+    // ---- step(): damped Schur system  S = A_l - SC = S0 + lambda diag(A),  rhs = g - sg  (row A8) ----
     const double lam = pow10_lg(st, st->lambda_lg10);
     double S[45], rhs[9], inv[9];
     bool freep[9];
 #pragma unroll
-    for (int a = 0; a < 9; a++) {
-        const double Aaa = st->A_prev[tri(a, a)];
-        freep[a] = st->mask[a] != 0 && Aaa > 0.0;   // fixed or unobservable parameter: delta = 0
-    }
+    for (int a = 0; a < 9; a++) freep[a] = st->mask[a] != 0 && rs[RED_DA + a] > 0.0;   // fixed / unobservable: delta = 0
 #pragma unroll
     for (int a = 0; a < 9; a++) {
 #pragma unroll
         for (int b = 0; b <= a; b++) {
-            double v = st->A_prev[tri(a, b)] - rs[RED_SC + tri(a, b)];
-            if (a == b) v = st->A_prev[tri(a, a)] * (1.0 + lam) - rs[RED_SC + tri(a, a)];
+            double v = rs[RED_S + tri(a, b)];
+            if (a == b) v += lam * rs[RED_DA + a];
             if (!(freep[a] && freep[b])) v = (a == b) ? 1.0 : 0.0;
             S[tri(a, b)] = v;
         }
-        rhs[a] = freep[a] ? st->g_prev[a] - rs[RED_SG + a] : 0.0;
+        rhs[a] = freep[a] ? rs[RED_GS + a] : 0.0;
     }
     const bool ok = chol_packed<9>(S, inv);
     if (!ok) {
@@ -393,8 +395,10 @@ __device__ void lm_advance(LmState *st, const double *rs, TraceRec *trace) {
 }
 
 constexpr int SOLVE_THREADS = 1024;
-constexpr int SOLVE_SLICES = SOLVE_THREADS / 128;
-constexpr int SOLVE_UNROLL = 32;
+constexpr int SOLVE_COLS = 64 + 8;                  // >= NRED, partial rows are read as 72-wide
+constexpr int SOLVE_SLICES = 14;                    // 14 x 72 = 1008 threads reduce
+constexpr int SOLVE_UNROLL = 24;
+static_assert(NRED <= SOLVE_COLS && SOLVE_SLICES * SOLVE_COLS <= SOLVE_THREADS, "reduce geometry");
 constexpr int STATE_WORDS = sizeof(LmState) / 8;
 static_assert(sizeof(LmState) % 8 == 0, "LmState is copied as 8-byte words");
 
@@ -406,19 +410,21 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_lm_solve(LmState *st, const d
                                                              double *red, TraceRec *trace, LmState *host_result,
                                                              unsigned long long *host_progress, int nblocks,
                                                              int do_reduce, int do_solve) {
-    __shared__ double part[SOLVE_SLICES][128];
+    __shared__ double part[SOLVE_SLICES][SOLVE_COLS];
     __shared__ double rs[NRED];
     __shared__ LmState ls;
+    STAMP2(0);
     if (st->done) return;
+    STAMP2(1);
     const int tid = threadIdx.x;
     for (int i = tid; i < STATE_WORDS; i += SOLVE_THREADS)
         reinterpret_cast<double *>(&ls)[i] = reinterpret_cast<const double *>(st)[i];
     if (do_reduce) {
-        // slice c adds blocks c, c + 8, ... of column j: SOLVE_UNROLL loads are put in flight
+        // slice c adds blocks c, c + 14, ... of column j: SOLVE_UNROLL loads are put in flight
         // together (one L2 round trip per group instead of one per block), then added in order
-        const int j = tid & 127, c = tid >> 7;
+        const int j = tid % SOLVE_COLS, c = tid / SOLVE_COLS;
         double s = 0.0;
-        if (j < NRED) {
+        if (j < NRED && c < SOLVE_SLICES) {
             for (int b0 = c; b0 < nblocks; b0 += SOLVE_SLICES * SOLVE_UNROLL) {
                 double v[SOLVE_UNROLL];
 #pragma unroll
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_lm_solve(LmState *st, const d
                 for (int k = 0; k < SOLVE_UNROLL; k++) s += v[k];
             }
         }
-        part[c][j] = s;
+        if (c < SOLVE_SLICES) part[c][j] = s;
         __syncthreads();
         if (tid < NRED) {
             double t = part[0][tid];
@@ -443,24 +449,24 @@ __global__ __launch_bounds__(SOLVE_THREADS) void k_lm_solve(LmState *st, const d
         rs[tid] = red[tid];
     }
     __syncthreads();
+    STAMP2(2);
     if (!do_solve) return;
     if (tid == 0) lm_advance(&ls, rs, trace);
+    STAMP2(3);
     __syncthreads();
-    const bool finished = ls.done != 0 && host_result != nullptr;
-    for (int i = tid; i < STATE_WORDS; i += SOLVE_THREADS) {
-        const double w = reinterpret_cast<const double *>(&ls)[i];
-        reinterpret_cast<double *>(st)[i] = w;
-        if (finished) reinterpret_cast<double *>(host_result)[i] = w;
-    }
-    if (host_progress != nullptr) {
-        // progress word for the host's spin-wait: (trials << 32) | done, published after the
-        // state words of every thread have reached host memory
-        if (finished) __threadfence_system();
-        __syncthreads();
+    for (int i = tid; i < STATE_WORDS; i += SOLVE_THREADS)
+        reinterpret_cast<double *>(st)[i] = reinterpret_cast<const double *>(&ls)[i];
+    if (host_progress != nullptr && tid < 64) {
+        // wave 0 alone talks to the host: the state header when the solve terminates, then the
+        // progress word (trials << 32) | done that the host spins on, released at system scope
+        static_assert(HOST_WORDS <= 64 && HOST_WORDS <= STATE_WORDS, "host mirror is written by one wave");
+        if (ls.done != 0 && host_result != nullptr && tid < HOST_WORDS)
+            reinterpret_cast<double *>(host_result)[tid] = reinterpret_cast<const double *>(&ls)[tid];
         if (tid == 0)
             __hip_atomic_store(host_progress, ((unsigned long long)(unsigned)ls.trials << 32) | (ls.done ? 1ull : 0ull),
                                __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    STAMP2(4);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -8,8 +8,8 @@
 //                             point ("prev"), 1-p the candidate being evaluated.  Per image (576 B):
 //                             rvec,tvec | U = C_l^-1 [B^T | h] for the lambda the next step uses
 //                             (back-substitution is then one 6x9 mat-vec) | pd flag
-//   partials [nblk][112] f64  per-workgroup partial sums of the reduced intrinsic system
-//   red      [112]      f64   the reduced system (what is all-reduced across GPUs)
+//   partials [nblk][68] f64   per-workgroup partial sums of the reduced intrinsic system
+//   red      [68]       f64   the reduced system (what is all-reduced across GPUs)
 //   LmState             the OpenCV CvLevMarq state machine, advanced on device
 #pragma once
 
@@ -17,15 +17,14 @@
 
 namespace ccal {
 
-constexpr int NRED = 112;      // doubles in the reduced system
-constexpr int RED_A = 0;       // A  = sum Ji^T Ji          packed lower 9x9 (45)
-constexpr int RED_G = 45;      // g  = sum Ji^T e           (9)
-constexpr int RED_SC = 54;     // SC = sum B C_l^-1 B^T     packed lower 9x9 (45)
-constexpr int RED_SG = 99;     // sg = sum B C_l^-1 h       (9)
-constexpr int RED_ERR = 108;   // sum ||e||^2
-constexpr int RED_DNUM = 109;  // sum ||ext_cand - ext_prev||^2
-constexpr int RED_DDEN = 110;  // sum ||ext_prev||^2
-constexpr int RED_BAD = 111;   // images with a non-PD block or non-finite error
+constexpr int NRED = 68;       // doubles in the reduced system (the all-reduced message: 544 B)
+constexpr int RED_S = 0;       // S0 = sum (Ji^T Ji - B C_l^-1 B^T)     packed lower 9x9 (45)
+constexpr int RED_DA = 45;     // diag(sum Ji^T Ji): Marquardt damping adds lambda * dA to diag(S0)   (9)
+constexpr int RED_GS = 54;     // sum (Ji^T e - B C_l^-1 h)                                           (9)
+constexpr int RED_ERR = 63;    // sum ||e||^2
+constexpr int RED_DNUM = 64;   // sum ||ext_cand - ext_prev||^2
+constexpr int RED_DDEN = 65;   // sum ||ext_prev||^2
+constexpr int RED_BAD = 66;    // images with a non-PD block or non-finite error (67: pad)
 
 // per-image block (doubles): everything the next sweep's prologue needs sits in the first 72
 // doubles, so one coalesced 576-B read per parity fetches it
@@ -42,9 +41,11 @@ enum : int { MODE_INIT = 0, MODE_EVAL = 1, MODE_RESCHUR = 2 };   // RESCHUR: re-
 constexpr int MAX_KINDS = 64;
 
 struct LmState {
+    // ---- header: the first HOST_WORDS 8-byte words are mirrored into pinned host memory by the
+    //      k_lm_solve that terminates the solve ----
     int32_t mode;          // what the NEXT sweep does
     int32_t done;
-    int32_t parity;        // ext/blk buffer holding the accepted point
+    int32_t parity;        // blk buffer holding the accepted point
     int32_t lambda_lg10;   // OpenCV lambdaLg10
     int32_t lg_partials;   // log10(lambda) the sweep must use for its Schur partials
     int32_t iters;
@@ -60,13 +61,15 @@ struct LmState {
     double lam_step;       // lambda of the step being evaluated (back-substitution)
     double lam_next;       // lambda for the Schur partials of this sweep
     double prev_err, rel_step;
-    double intr_prev[9], intr_cand[9], dint[9];
+    double intr_prev[9];
+    int32_t kinds[MAX_KINDS];   // per trial: 1 + mode of the sweep it ran (0 = no-op after `done`)
+    // ---- device only ----
+    double intr_cand[9], dint[9];
     int32_t mask[9];
     int32_t pad_;
-    double A_prev[45], g_prev[9];
-    int32_t kinds[MAX_KINDS];   // per trial: 1 + mode of the sweep it ran (0 = no-op after `done`)
     double pow10[33];           // lambda table 10^(lg), lg = -16..16, filled by k_lm_begin
 };
+constexpr int HOST_WORDS = 64;  // covers everything up to and including kinds[]
 
 // Everything k_lm_begin needs to (re)build LmState on the device; passed by value as a kernel
 // argument so that a whole solve (begin + trials + read-back) is one replayable hipGraph.

@@ -1,5 +1,5 @@
 """Multi-GPU plumbing: images shard one-extrinsic-block-per-GPU; the only
-exchange is an all-reduce (sum, FP64) of the 112-double reduced intrinsic system per LM
+exchange is an all-reduce (sum, FP64) of the 68-double reduced intrinsic system per LM
 trial, plus one 8-double all-reduce for the initial focal lengths.  One process per GPU,
 `torch.distributed` (backend "nccl" == RCCL over xGMI; "gloo" for the CPU tests).
 """
@@ -69,7 +69,7 @@ def broadcast_id_via_torch(group=None):
 
 
 def reduced_system_from_gram(G, lam, mask=None):
-    """numpy mirror of one image's contribution to the 112-double reduced system of the device
+    """numpy mirror of one image's contribution to the 68-double reduced system of the device
     kernels: A, g, SC = B C_l^-1 B^T, sg = B C_l^-1 h, err.  Used by the CPU
     tests of the sharding logic; G is the 16x16 Gram [Je|Ji|e]^T[Je|Ji|e]."""
     C = G[:6, :6].copy()

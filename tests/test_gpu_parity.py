@@ -302,3 +302,67 @@ def test_allreduce_paths_world1():
         assert r["iters"] == base["iters"] and r["rms"] == base["rms"]
         for k in ("intr", "rvecs", "tvecs"):
             assert np.array_equal(r[k], base[k]), k
+
+
+FLAG_CASES = [
+    # (flags, aspect, use_guess)
+    (syn.FIX_ASPECT_RATIO | syn.ZERO_TANGENT_DIST | syn.FIX_K2 | syn.FIX_K3, 1.25, False),   # reference word, aspect != 1
+    (syn.FIX_PRINCIPAL_POINT | syn.FIX_K3, 1.0, False),
+    (syn.FIX_FOCAL_LENGTH | syn.FIX_K2 | syn.FIX_K3 | syn.ZERO_TANGENT_DIST, 1.0, True),
+    (syn.FIX_TANGENT_DIST | syn.FIX_K1, 1.0, True),
+    (syn.USE_INTRINSIC_GUESS | syn.FIX_ASPECT_RATIO | syn.FIX_K3, 1.0, True),
+    (0, 1.0, False),                                                                            # full 9-parameter model
+]
+
+
+@pytest.mark.parametrize("flags,aspect,use_guess", FLAG_CASES)
+def test_flag_words_match_oracle(flags, aspect, use_guess):
+    """Parameter masks of SURVEY.md A.1 (every supported flag bit), incl. intrinsic guesses
+    with non-zero distortion (undistortion in the pose initialisation) -- vs the oracle."""
+    wl = syn.make_workload("flags", (9, 6), 14, "full", seed=99, aspect=1.0)
+    if flags & syn.FIX_ASPECT_RATIO and not use_guess:
+        wl = syn.make_workload("flags", (9, 6), 14, "ref", seed=99, aspect=aspect)
+    guess = None
+    if use_guess:
+        flags |= syn.USE_INTRINSIC_GUESS
+        guess = wl.intr_true * np.array([1.01, 0.99, 1.002, 0.998, 0.9, 1.1, 1.0, 1.0, 1.0])
+    ro = orc.calibrate(wl.obj, wl.img, wl.image_size, aspect=aspect, flags=flags, max_iter=30, eps=1e-6,
+                       solver="schur", init_intr=guess)
+    with Solver(0) as s:
+        s.set_problem(wl.obj, wl.n_images, wl.image_size, aspect=aspect, flags=flags, max_iter=30, eps=1e-6)
+        s.set_image_points(wl.img)
+        st, r = s.calibrate(init_intr=guess)
+    assert st in (0, 1)
+    assert r["iters"] == ro["iters"]
+    assert abs(r["rms"] - ro["rms"]) < 1e-8
+    assert np.abs(r["intr"][:4] - ro["intr"][:4]).max() / ro["intr"][1] < 1e-6
+    assert np.abs(r["intr"][4:] - ro["intr"][4:]).max() < 1e-5
+    assert np.abs(r["rvecs"] - ro["rvecs"]).max() < 1e-5 and np.abs(r["tvecs"] - ro["tvecs"]).max() < 1e-4
+    # masked parameters did not move
+    fixed = []
+    if flags & syn.FIX_K1: fixed.append(4)
+    if flags & syn.FIX_K2: fixed.append(5)
+    if flags & syn.FIX_K3: fixed.append(8)
+    if flags & (syn.ZERO_TANGENT_DIST | syn.FIX_TANGENT_DIST): fixed += [6, 7]
+    if flags & syn.FIX_PRINCIPAL_POINT: fixed += [2, 3]
+    if flags & syn.FIX_FOCAL_LENGTH: fixed += [0, 1]
+    start = guess if guess is not None else np.r_[ro["init_intr"]]
+    for a in fixed:
+        want = 0.0 if (a in (6, 7) and flags & syn.ZERO_TANGENT_DIST) else start[a]
+        assert r["intr"][a] == want, a
+    if flags & syn.FIX_ASPECT_RATIO:
+        asp = (guess[0] / guess[1]) if use_guess else aspect
+        assert abs(r["intr"][0] / r["intr"][1] - asp) < 1e-12
+
+
+def test_non_finite_input_is_reported():
+    from cameracalibrations_amd import _ffi as F
+    wl = syn.named_workload("C1", n_images=5)
+    bad = wl.img.copy()
+    bad[2, 7, 0] = np.nan
+    with Solver(0) as s:
+        s.set_problem(wl.obj, 5, wl.image_size, flags=wl.flags)
+        s.set_image_points(bad)
+        with pytest.raises(F.CcalError) as e:
+            s.calibrate()
+        assert e.value.code in (F.E_NONFINITE, F.E_DEGENERATE)

@@ -37,3 +37,6 @@ with Solver(0) as s:
         print("total cycles", t[10] - t[0], "(%.2f us at 2.4 GHz)" % ((t[10] - t[0]) / 2400.0))
         for n, v in zip(names[1:], d):
             print(f"   {n:24s} {v:7d}")
+        t2 = np.array(buf[16:21], dtype=np.int64)
+        print("solve kernel (thread 0):", dict(zip(["done-check", "state+partials+reduce", "lm_advance", "write-back"],
+                                                   np.diff(t2).tolist())), "total", t2[4] - t2[0])
