@@ -26,6 +26,11 @@ using namespace ccal;
 namespace ccal { hipError_t debug_read_stamps(unsigned long long *out); }
 #endif
 
+// prologue reduction: every workgroup sums the previous partials itself while they are few; beyond
+// DIRECT_MAX_BLOCKS (or when the sum has to leave the GPU) k_lm_reduce condenses them first
+static constexpr int DIRECT_MAX_BLOCKS = 320;
+static constexpr int REDUCE_ROWS = 64;
+
 static thread_local std::string g_err;
 
 static int fail(int code, const std::string &msg) {
@@ -83,7 +88,7 @@ struct ccal_ctx {
     std::vector<hipEvent_t> ev;   // 2 * MAX_KINDS events, created on demand
     int ev_used = 0;
     // one solve = one replayable graph: begin + lm_batch x (sweep, solve) + state read-back
-    hipGraphExec_t g_first = nullptr, g_cont = nullptr;
+    hipGraphExec_t g_first = nullptr;
     double dbg_enqueue_s = 0, dbg_total_s = 0;
     int dbg_runs = 0;
     bool graph_dirty = true, use_graph = true, adaptive_batch = true, spin_wait = true;
@@ -130,9 +135,9 @@ int ccal_create(int device, ccal_ctx **out) {
     c->device = device;
     HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
-    HIPCHK(hipMalloc(&c->d_st, sizeof(LmState)));
-    HIPCHK(hipMalloc(&c->d_st_scratch, sizeof(LmState)));
-    HIPCHK(hipMalloc(&c->d_red, sizeof(double) * NRED));
+    HIPCHK(hipMalloc(&c->d_st, sizeof(LmState) * 2));          // S_k lives in d_st[k & 1]
+    HIPCHK(hipMalloc(&c->d_st_scratch, sizeof(LmState) * 2));
+    HIPCHK(hipMalloc(&c->d_red, sizeof(double) * NRED * REDUCE_ROWS));
     HIPCHK(hipMalloc(&c->d_foc_red, sizeof(double) * NFOC));
     HIPCHK(hipMalloc(&c->d_fail, sizeof(int) * 4));
     HIPCHK(hipMalloc(&c->d_intr0, sizeof(double) * 9));
@@ -158,7 +163,6 @@ void ccal_destroy(ccal_ctx *c) {
     (void)hipFree(c->d_st); (void)hipFree(c->d_st_scratch); (void)hipFree(c->d_red); (void)hipFree(c->d_foc_red); (void)hipFree(c->d_fail);
     (void)hipFree(c->d_trace); (void)hipFree(c->d_intr0); (void)hipFree(c->d_intr_scratch);
     if (c->g_first) (void)hipGraphExecDestroy(c->g_first);
-    if (c->g_cont) (void)hipGraphExecDestroy(c->g_cont);
     (void)hipHostFree(c->h_st); (void)hipHostFree(c->h_flags);
     for (auto &e : c->ev) (void)hipEventDestroy(e);
     delete c->comm;
@@ -240,7 +244,7 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
         HIPCHK(hipMalloc(&c->d_obj, sizeof(float) * 3 * P));
         HIPCHK(hipMalloc(&c->d_ext0, sizeof(double) * n * EXT));
         HIPCHK(hipMalloc(&c->d_blk, sizeof(double) * 2 * n * BLK));
-        HIPCHK(hipMalloc(&c->d_partials, sizeof(double) * (size_t)lm_sweep_blocks(N) * NRED));
+        HIPCHK(hipMalloc(&c->d_partials, sizeof(double) * 2 * (size_t)lm_sweep_blocks(N) * NRED));
         HIPCHK(hipMalloc(&c->d_H, sizeof(double) * n * 9));
         HIPCHK(hipMalloc(&c->d_foc_partials, sizeof(double) * n * NFOC));
         c->n_cap = n;
@@ -439,36 +443,59 @@ static int wait_progress(ccal_ctx *c, long target_trials) {
     return CCAL_OK;
 }
 
-static int enqueue_trial(ccal_ctx *c, hipStream_t stream) {
-    const bool timed = c->time_sweeps && c->ev_used < MAX_KINDS;
-    if (timed) HIPCHK(hipEventRecord(c->ev[2 * c->ev_used], stream));
-    HIPCHK(launch_lm_sweep(stream, c->d_obj, c->d_img, c->d_blk, c->d_st, c->d_partials, nullptr, c->N, c->P));
-    if (timed) HIPCHK(hipEventRecord(c->ev[2 * c->ev_used++ + 1], stream));
+static TrialLaunch base_launch(ccal_ctx *c) {
+    TrialLaunch t;
+    t.obj = c->d_obj; t.img = c->d_img; t.blk = c->d_blk; t.st = c->d_st; t.partials = c->d_partials;
+    t.trace = c->d_trace; t.host_result = c->h_st; t.host_progress = progress_word(c);
+    t.intr0 = c->d_intr0; t.ext0 = c->d_ext0; t.ext0_stride = EXT; t.init = make_init(c);
+    t.N = c->N; t.P = c->P;
+    return t;
+}
+
+// Launch trial k (k_lm_trial): its prologue consumes the partials of trial k - 1 -- directly, or
+// condensed by k_lm_reduce (many workgroups), or all-reduced across GPUs (sharded fits).
+static int enqueue_trial(ccal_ctx *c, hipStream_t stream, int k, bool final_only) {
+    TrialLaunch t = base_launch(c);
+    t.k = k;
+    t.first = k == 0;
+    t.final_only = final_only ? 1 : 0;
     const int nb = lm_sweep_blocks(c->N);
-    if (sharded(c)) {
-        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, nullptr, nullptr, nb, 1, 0));
-        const int rc = run_allreduce(c, c->d_red, NRED);
-        if (rc) return rc;
-        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, c->h_st, progress_word(c), nb, 0, 1));
-    } else {
-        HIPCHK(launch_lm_solve(stream, c->d_st, c->d_partials, c->d_red, c->d_trace, c->h_st, progress_word(c), nb, 1, 1));
+    if (k > 0) {
+        const double *prev = c->d_partials + (size_t)((k - 1) & 1) * nb * NRED;
+        if (sharded(c)) {
+            HIPCHK(launch_lm_reduce(stream, prev, nb, c->d_red, 1));
+            const int rc = run_allreduce(c, c->d_red, NRED);
+            if (rc) return rc;
+            t.rows_in = c->d_red;
+            t.n_in = 1;
+        } else if (nb > DIRECT_MAX_BLOCKS) {
+            HIPCHK(launch_lm_reduce(stream, prev, nb, c->d_red, REDUCE_ROWS));
+            t.rows_in = c->d_red;
+            t.n_in = REDUCE_ROWS;
+        } else {
+            t.rows_in = prev;
+            t.n_in = nb;
+        }
     }
+    if (!final_only && c->time_sweeps && c->ev_used < MAX_KINDS) {
+        t.ev_start = c->ev[2 * c->ev_used];
+        t.ev_stop = c->ev[2 * c->ev_used + 1];
+        c->ev_used++;
+    }
+    HIPCHK(launch_lm_trial(stream, t));
     return CCAL_OK;
 }
 
-// Capture [begin] + lm_batch trials into an executable graph.  The terminating k_lm_solve writes
-// the final state straight into the pinned host mirror, so there is no copy node.
-static int capture_graph(ccal_ctx *c, bool with_begin, hipGraphExec_t *out) {
+// Capture trials 0 .. lm_batch-1 plus the terminating prologue-only launch into one graph.
+static int capture_graph(ccal_ctx *c, hipGraphExec_t *out) {
     hipGraph_t graph = nullptr;
     hipStream_t cs = c->own_stream;
     HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
     int rc = CCAL_OK;
-    hipError_t e = hipSuccess;
-    if (with_begin) e = launch_lm_begin(cs, c->d_st, make_init(c), c->d_intr0, c->d_ext0, EXT, c->d_blk);
-    for (int b = 0; b < c->lm_batch && e == hipSuccess && rc == CCAL_OK; b++) rc = enqueue_trial(c, cs);
+    for (int k = 0; k < c->lm_batch && rc == CCAL_OK; k++) rc = enqueue_trial(c, cs, k, false);
+    if (rc == CCAL_OK) rc = enqueue_trial(c, cs, c->lm_batch, true);
     const hipError_t e2 = hipStreamEndCapture(cs, &graph);
     if (rc != CCAL_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    HIPCHK(e);
     HIPCHK(e2);
     if (*out) { (void)hipGraphExecDestroy(*out); *out = nullptr; }
     HIPCHK(hipGraphInstantiate(out, graph, nullptr, nullptr, 0));
@@ -483,7 +510,7 @@ int ccal_lm_run(ccal_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     const double t0 = now_s();
     // upper bound on trials: every accepted iteration may be preceded by lambda climbing
-    // from -16 to 16 (rejections + re-Schur passes)
+    // from -16 to 16 (rejections + re-damping sweeps)
     const long max_trials = 8L + (long)c->max_iter * 70L;
     long trials = 0;
     c->ev_used = 0;
@@ -492,36 +519,34 @@ int ccal_lm_run(ccal_ctx *c) {
     const bool graphed = c->use_graph && !c->time_sweeps && !sharded(c);
     if (graphed && c->graph_dirty) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        int rc = capture_graph(c, true, &c->g_first);
-        if (rc == CCAL_OK) rc = capture_graph(c, false, &c->g_cont);
+        const int rc = capture_graph(c, &c->g_first);
         if (rc) return rc;
         c->graph_dirty = false;
     }
     const double t_enq0 = now_s();
     if (graphed) {
         HIPCHK(hipGraphLaunch(c->g_first, c->stream));
-        c->dbg_enqueue_s += now_s() - t_enq0;
-        trials += c->lm_batch;
-        int rc = wait_progress(c, trials);
-        if (rc) return rc;
-        while (!c->h_st->done && trials < max_trials) {
-            HIPCHK(hipGraphLaunch(c->g_cont, c->stream));
-            trials += c->lm_batch;
-            if ((rc = wait_progress(c, trials)) != CCAL_OK) return rc;
-        }
+        trials = c->lm_batch;
     } else {
-        HIPCHK(launch_lm_begin(c->stream, c->d_st, make_init(c), c->d_intr0, c->d_ext0, EXT, c->d_blk));
-        while (trials < max_trials) {
-            for (int b = 0; b < c->lm_batch; b++) {
-                const int rc = enqueue_trial(c, c->stream);
-                if (rc) return rc;
-            }
-            if (trials == 0) c->dbg_enqueue_s += now_s() - t_enq0;
-            trials += c->lm_batch;
-            const int rc = wait_progress(c, trials);
+        for (int k = 0; k < c->lm_batch; k++) {
+            const int rc = enqueue_trial(c, c->stream, k, false);
             if (rc) return rc;
-            if (c->h_st->done) break;
         }
+        trials = c->lm_batch;
+        const int rc = enqueue_trial(c, c->stream, (int)trials, true);
+        if (rc) return rc;
+    }
+    c->dbg_enqueue_s += now_s() - t_enq0;
+    int rc = wait_progress(c, trials);
+    if (rc) return rc;
+    // the graph was sized for another problem: continue trial by trial (the next solve re-captures)
+    while (!c->h_st->done && trials < max_trials) {
+        const int more = c->lm_batch < 4 ? 4 : c->lm_batch;
+        for (int k = 0; k < more; k++)
+            if ((rc = enqueue_trial(c, c->stream, (int)trials + k, false)) != CCAL_OK) return rc;
+        trials += more;
+        if ((rc = enqueue_trial(c, c->stream, (int)trials, true)) != CCAL_OK) return rc;
+        if ((rc = wait_progress(c, trials)) != CCAL_OK) return rc;
     }
     const LmState &r = *c->h_st;
     c->stats.t_lm_s = now_s() - t0;
@@ -535,11 +560,13 @@ int ccal_lm_run(ccal_ctx *c) {
     c->stats.rms = std::sqrt(r.prev_err / ((double)r.N_global * (double)c->P));
     c->stats.sweep_us = 0.0;
     c->stats.timed_sweeps = 0;
+    if (!r.done) return fail(CCAL_E_STATE, "ccal_lm_run: trial budget exhausted without termination");
     if (c->time_sweeps) {
+        HIPCHK(hipStreamSynchronize(c->stream));
         double sum_ms = 0.0;
         int n = 0;
         for (int t = 0; t < c->ev_used; t++) {
-            if (r.kinds[t] != 1 + MODE_INIT && r.kinds[t] != 1 + MODE_EVAL) continue;   // re-Schur / no-op launches
+            if (r.kinds[t] != 1 + MODE_INIT && r.kinds[t] != 1 + MODE_EVAL) continue;   // re-damping / surplus launches
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * t], c->ev[2 * t + 1]));
             sum_ms += ms;
@@ -548,12 +575,11 @@ int ccal_lm_run(ccal_ctx *c) {
         c->stats.timed_sweeps = n;
         c->stats.sweep_us = n ? 1000.0 * sum_ms / n : 0.0;
     }
-    if (!r.done) return fail(CCAL_E_STATE, "ccal_lm_run: trial budget exhausted without termination");
     c->have_result = true;
-    // size the next graph to the trials this problem needed (no-op launches after `done` cost
-    // a kernel boundary each); a different problem simply continues with g_cont
+    // size the next graph to the trials this problem needed (a surplus launch costs a kernel
+    // boundary); a different problem simply continues trial by trial above
     if (c->adaptive_batch && r.trials != c->lm_batch) {
-        c->lm_batch = r.trials < 2 ? 2 : (r.trials > 32 ? 32 : r.trials);
+        c->lm_batch = r.trials < 1 ? 1 : (r.trials > 48 ? 48 : r.trials);
         c->graph_dirty = true;
     }
     if (r.status == -4) return fail(CCAL_E_NONFINITE, "ccal_lm_run: non-finite reprojection error on the device");
@@ -752,9 +778,10 @@ int ccal_debug_image_grams(ccal_ctx *c, const double intr[CCAL_NINTR], const dou
     if (rc) return rc;
     if (!c->d_gram) HIPCHK(hipMalloc(&c->d_gram, sizeof(double) * c->n_cap * 256));
     HIPCHK(hipMemcpyAsync(c->d_intr_scratch, intr, sizeof(double) * 9, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(launch_lm_begin(c->stream, c->d_st_scratch, make_init(c), c->d_intr_scratch, c->d_ext0, EXT, c->d_blk));
-    HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_blk, c->d_st_scratch, c->d_partials, c->d_gram, c->N,
-                           c->P));
+    TrialLaunch t = base_launch(c);
+    t.st = c->d_st_scratch; t.trace = nullptr; t.host_result = nullptr; t.host_progress = nullptr;
+    t.intr0 = c->d_intr_scratch; t.gram_out = c->d_gram; t.first = 1; t.k = 0;
+    HIPCHK(launch_lm_trial(c->stream, t));
     HIPCHK(hipMemcpyAsync(G_host, c->d_gram, sizeof(double) * (size_t)c->N * 256, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     c->have_result = false;
@@ -766,32 +793,30 @@ int ccal_time_sweep(ccal_ctx *c, int32_t reps, double *avg_us) {
     if (!c->have_problem || !c->have_img || !c->have_intr || !c->have_ext)
         return fail(CCAL_E_STATE, "ccal_time_sweep: needs image points and a parameter point");
     HIPCHK(hipSetDevice(c->device));
-    // evaluate at the last result if there is one, else at the initial values
-    const double *intr = c->d_intr0, *ext_src = c->d_ext0;
-    int stride = EXT;
+    // a first-trial launch (state boot + full sweep) at the last result if there is one, else at the
+    // initial values; back-to-back launches, so the mean includes one kernel boundary
+    TrialLaunch t = base_launch(c);
+    t.st = c->d_st_scratch; t.trace = nullptr; t.host_result = nullptr; t.host_progress = nullptr;
+    t.first = 1; t.k = 0;
     if (c->have_result) {
-        intr = reinterpret_cast<const double *>(reinterpret_cast<const char *>(c->d_st) + offsetof(LmState, intr_prev));
-        ext_src = c->d_blk + (size_t)c->h_st->parity * c->N * BLK;
-        stride = BLK;
+        const LmState *fin = c->d_st + (c->h_st->trials & 1);
+        t.intr0 = reinterpret_cast<const double *>(reinterpret_cast<const char *>(fin) + offsetof(LmState, intr_prev));
+        t.ext0 = c->d_blk + (size_t)c->h_st->parity * c->N * BLK;
+        t.ext0_stride = BLK;
     }
-    HIPCHK(launch_lm_begin(c->stream, c->d_st_scratch, make_init(c), intr, ext_src, stride, c->d_blk));
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0));
     HIPCHK(hipEventCreate(&e1));
-    for (int w = 0; w < 3; w++)
-        HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_blk, c->d_st_scratch, c->d_partials, nullptr, c->N,
-                               c->P));
+    for (int w = 0; w < 3; w++) HIPCHK(launch_lm_trial(c->stream, t));
     HIPCHK(hipEventRecord(e0, c->stream));
-    for (int r = 0; r < reps; r++)
-        HIPCHK(launch_lm_sweep(c->stream, c->d_obj, c->d_img, c->d_blk, c->d_st_scratch, c->d_partials, nullptr, c->N,
-                               c->P));
+    for (int r = 0; r < reps; r++) HIPCHK(launch_lm_trial(c->stream, t));
     HIPCHK(hipEventRecord(e1, c->stream));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    c->have_result = false;   // ext[0] / blk[0] now hold the timed point, not the fit's buffers
+    c->have_result = false;   // blk[0] heads now hold the timed point, not the fit's buffers
     *avg_us = 1000.0 * ms / reps;
     return CCAL_OK;
 }

@@ -9,13 +9,25 @@ namespace ccal {
 
 // ccal_lm.hip
 int lm_sweep_blocks(int N);
-hipError_t launch_lm_begin(hipStream_t stream, LmState *st, const LmInit &init, const double *intr0, const double *ext0,
-                           int ext0_stride, double *blk);
-hipError_t launch_lm_sweep(hipStream_t stream, const float *obj, const float *img, double *blk, const LmState *st,
-                           double *partials, double *gram_out, int N, int P);
-hipError_t launch_lm_solve(hipStream_t stream, LmState *st, const double *partials, double *red, TraceRec *trace,
-                           LmState *host_result, unsigned long long *host_progress, int nblocks, int do_reduce,
-                           int do_solve);
+struct TrialLaunch {              // one launch of k_lm_trial (see ccal_lm.hip)
+    const float *obj = nullptr, *img = nullptr;
+    double *blk = nullptr;
+    LmState *st = nullptr;        // [2]
+    double *partials = nullptr;   // [2][nblocks][NRED]
+    const double *rows_in = nullptr;
+    int n_in = 0;
+    TraceRec *trace = nullptr;
+    LmState *host_result = nullptr;
+    unsigned long long *host_progress = nullptr;
+    const double *intr0 = nullptr, *ext0 = nullptr;
+    int ext0_stride = EXT;
+    LmInit init{};
+    double *gram_out = nullptr;
+    int N = 0, P = 0, k = 0, first = 0, final_only = 0;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // optional: timestamps of this dispatch
+};
+hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t);
+hipError_t launch_lm_reduce(hipStream_t stream, const double *rows, int n_rows, double *out, int G);
 
 // ccal_init.hip -- closed-form initialisation
 constexpr int NFOC = 8;   // doubles all-reduced for the focal least squares: AtA(3) Atb(2) fail(1) pad(2)

@@ -22,8 +22,8 @@ from cameracalibrations_amd.solver import Solver  # noqa: E402
 L = F.lib()
 L.ccal_debug_stamps.restype = C.c_int
 wl = syn.named_workload("C3")
-names = ["entry->done-check", "setup", "prologue (backsubst)", "rodrigues", "point_rows", "tile store+sync",
-         "mfma gram+sync", "Gs sync", "chol+fwd+sync", "block store", "red + partial"]
+names = ["entry", "state + reduce partials + advance", "head -> pose (backsubst)", "rotation R,K", "point_rows",
+         "tile store", "mfma gram", "Gram -> LDS", "chol6 + U + Y", "block store", "outputs + WG partial"]
 with Solver(0) as s:
     s.set_problem(wl.obj, wl.n_images, wl.image_size, aspect=wl.aspect, flags=wl.flags)
     s.set_image_points(wl.img)
@@ -37,6 +37,8 @@ with Solver(0) as s:
         print("total cycles", t[10] - t[0], "(%.2f us at 2.4 GHz)" % ((t[10] - t[0]) / 2400.0))
         for n, v in zip(names[1:], d):
             print(f"   {n:24s} {v:7d}")
-        t2 = np.array(buf[16:21], dtype=np.int64)
-        print("solve kernel (thread 0):", dict(zip(["done-check", "state+partials+reduce", "lm_advance", "write-back"],
-                                                   np.diff(t2).tolist())), "total", t2[4] - t2[0])
+        t = np.array(buf[:13], dtype=np.int64)
+        print("   prologue: state load", t[11] - t[0], "reduce", t[12] - t[11], "advance+sync", t[1] - t[12])
+        a = np.array(buf[16:20], dtype=np.int64)
+        print("   advance: state machine", a[0] - t[12], "assemble S", a[1] - a[0], "chol9", a[2] - a[1], "solves", a[3] - a[2],
+              "tail", t[1] - a[3])
