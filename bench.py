@@ -34,6 +34,17 @@ def algorithmic_bytes_per_sweep(N, P):
     return N * P * (8.0 + 96.0 / P)
 
 
+def pmc_traffic_bytes(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
+    command (tools/pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, both calibrated on a
+    known byte count with this code's access width).  None if the summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_summary.json")
+    try:
+        return float(json.load(open(path))[kernel]["hbm_bytes_per_launch"])
+    except Exception:      # noqa: BLE001
+        return None
+
+
 def cpu_baseline(wl, criteria, budget_s=12.0):
     """The oracle (plain-C port of the reference algorithm, Schur mode, OpenMP over images)
     timed on the host cores on the same workload; repeats until ~budget_s of CPU work."""
@@ -201,7 +212,8 @@ def main():
             "init": {"intrinsics_ms": 1e3 * rf["t_init_intr_s"], "extrinsics_ms": 1e3 * rf["t_init_extr_s"],
                      "full_fit_ms": fit_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic_bytes("ccal::k_lm_trial") if (N, P) == (1000, 54) else None,
                          "kernel": "ccal::k_lm_trial", "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": sweep_us, "launches_timed": n_timed,
                          "avg_launch_us_back_to_back": sweep_us_b2b,

@@ -17,7 +17,10 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             for row in csv.DictReader(open(f)):
                 if row.get("Counter_Name") != ctr:
                     continue
-                vals.setdefault(row["Kernel_Name"].split("(")[0], []).append(float(row["Counter_Value"]))
+                name = row["Kernel_Name"].split("(")[0]
+                if name == "ccal::k_lm_trial" and int(row["Grid_Size"]) <= 256:
+                    name += "[prologue-only]"       # the terminating launch of a solve: one workgroup, no sweep
+                vals.setdefault(name, []).append(float(row["Counter_Value"]))
         out[tag + ctr] = {k: dict(n=len(v), mean=statistics.mean(v), median=statistics.median(v)) for k, v in vals.items()}
 calib_bytes = float(1 << 31)
 summary = {}
@@ -26,10 +29,10 @@ w_unit = out.get("calib_WRITE_SIZE", {}).get("k_write8", {}).get("mean")
 summary["calibration"] = {"bytes": calib_bytes, "FETCH_SIZE_units_for_read": f_unit, "WRITE_SIZE_units_for_write": w_unit,
                           "bytes_per_FETCH_unit": calib_bytes / f_unit if f_unit else None,
                           "bytes_per_WRITE_unit": calib_bytes / w_unit if w_unit else None}
-for k in ("ccal::k_lm_sweep", "ccal::k_lm_solve"):
+for k in ("ccal::k_lm_trial", "ccal::k_lm_reduce"):
     fs = out.get("FETCH_SIZE", {}).get(k)
     ws = out.get("WRITE_SIZE", {}).get(k)
-    if fs and ws:
+    if fs and ws:  # noqa
         bf = summary["calibration"]["bytes_per_FETCH_unit"] or 1024.0
         bw = summary["calibration"]["bytes_per_WRITE_unit"] or 1024.0
         summary[k] = {"launches": fs["n"], "FETCH_SIZE_mean": fs["mean"], "WRITE_SIZE_mean": ws["mean"],
