@@ -30,6 +30,7 @@ namespace ccal { hipError_t debug_read_stamps(unsigned long long *out); }
 // DIRECT_MAX_BLOCKS (or when the sum has to leave the GPU) k_lm_reduce condenses them first
 static constexpr int DIRECT_MAX_BLOCKS = 320;
 static constexpr int REDUCE_ROWS = 64;
+static constexpr int SHARD_ROWS = 16;
 
 static thread_local std::string g_err;
 
@@ -424,11 +425,13 @@ static unsigned long long *progress_word(ccal_ctx *c) { return reinterpret_cast<
 
 // Wait until the device reports `done` or `target_trials` executed trials.  Spinning on the
 // pinned progress word avoids the wake-up latency of hipStreamSynchronize (tens of microseconds,
-// comparable to a whole solve); it falls back to a stream synchronisation after ~50 ms.
+// comparable to a whole small solve); after 200 us of spinning the solve is long enough for that
+// latency not to matter and the wait becomes a blocking stream synchronisation.
 static int wait_progress(ccal_ctx *c, long target_trials) {
     volatile unsigned long long *p = progress_word(c);
     if (c->spin_wait) {
-        for (long spins = 0; spins < 40000000L; spins++) {
+        const double t_end = now_s() + 200e-6;
+        for (long spins = 0;; spins++) {
             const unsigned long long v = *p;
             if ((v & 1ull) || (long)(v >> 32) >= target_trials) {
                 std::atomic_thread_fence(std::memory_order_acquire);
@@ -437,6 +440,7 @@ static int wait_progress(ccal_ctx *c, long target_trials) {
 #if defined(__x86_64__)
             __builtin_ia32_pause();
 #endif
+            if ((spins & 255) == 255 && now_s() > t_end) break;
         }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -463,11 +467,14 @@ static int enqueue_trial(ccal_ctx *c, hipStream_t stream, int k, bool final_only
     if (k > 0) {
         const double *prev = c->d_partials + (size_t)((k - 1) & 1) * nb * NRED;
         if (sharded(c)) {
-            HIPCHK(launch_lm_reduce(stream, prev, nb, c->d_red, 1));
-            const int rc = run_allreduce(c, c->d_red, NRED);
+            // 16 workgroups condense the partials (one would be bound by a single CU's ~64 GB/s); the
+            // 16 rows (8.7 KB, still latency-bound) are summed across GPUs and added up in the prologue
+            const int rows = nb < SHARD_ROWS ? nb : SHARD_ROWS;
+            HIPCHK(launch_lm_reduce(stream, prev, nb, c->d_red, rows));
+            const int rc = run_allreduce(c, c->d_red, NRED * rows);
             if (rc) return rc;
             t.rows_in = c->d_red;
-            t.n_in = 1;
+            t.n_in = rows;
         } else if (nb > DIRECT_MAX_BLOCKS) {
             HIPCHK(launch_lm_reduce(stream, prev, nb, c->d_red, REDUCE_ROWS));
             t.rows_in = c->d_red;
