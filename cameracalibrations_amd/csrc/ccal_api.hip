@@ -90,6 +90,12 @@ struct ccal_ctx {
     int ev_used = 0;
     // one solve = one replayable graph: begin + lm_batch x (sweep, solve) + state read-back
     hipGraphExec_t g_first = nullptr;
+    struct GraphKey {             // everything baked into the captured launches
+        const void *obj, *img, *blk, *st, *partials, *red, *trace, *intr0, *ext0;
+        int N, P, batch;
+        LmInit init;
+    } graph_key{};
+    bool defer_sync = false;      // one-shot path: stage syncs and checks are batched at the end
     double dbg_enqueue_s = 0, dbg_total_s = 0;
     int dbg_runs = 0;
     bool graph_dirty = true, use_graph = true, adaptive_batch = true, spin_wait = true;
@@ -145,7 +151,7 @@ int ccal_create(int device, ccal_ctx **out) {
     HIPCHK(hipMalloc(&c->d_intr_scratch, sizeof(double) * 9));
     HIPCHK(hipMalloc(&c->d_trace, sizeof(TraceRec) * c->max_trace));
     HIPCHK(hipHostMalloc(&c->h_st, sizeof(LmState), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc(&c->h_flags, sizeof(int) * 16, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&c->h_flags, sizeof(int) * 64, hipHostMallocDefault));   // flags | intr staging | progress
     const char *b = getenv("CCAL_LM_BATCH");
     if (b && atoi(b) > 0) { c->lm_batch = atoi(b); c->adaptive_batch = false; }
     const char *g = getenv("CCAL_NO_GRAPH");
@@ -254,11 +260,10 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
     HIPCHK(hipMemcpyAsync(c->d_obj, obj, sizeof(float) * 3 * P, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemsetAsync(c->d_blk, 0, sizeof(double) * 2 * (size_t)N * BLK, c->stream));
     HIPCHK(hipMemsetAsync(c->d_ext0, 0, sizeof(double) * (size_t)N * EXT, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));   // `obj` may be released by the caller after return
+    if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));   // `obj` may be released by the caller after return
     c->P = P; c->N = N; c->width = width; c->height = height; c->aspect = aspect; c->flags = flags;
     c->max_iter = max_iter; c->eps = eps;
     c->have_problem = true;
-    c->graph_dirty = true;
     c->have_img = c->have_intr = c->have_ext = c->have_result = false;
     c->d_img = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
@@ -278,8 +283,7 @@ int ccal_set_image_points(ccal_ctx *c, const float *img_host) {
         c->img_cap = need;
     }
     HIPCHK(hipMemcpyAsync(c->d_img_own, img_host, need, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    c->graph_dirty = c->graph_dirty || c->d_img != c->d_img_own;
+    if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));
     c->d_img = c->d_img_own;
     c->have_img = true;
     c->have_result = false;
@@ -294,7 +298,6 @@ int ccal_set_image_points_device(ccal_ctx *c, const float *img_device) {
         (void)hipGetLastError();
         return fail(CCAL_E_ARG, "ccal_set_image_points_device: not a device pointer");
     }
-    c->graph_dirty = c->graph_dirty || c->d_img != img_device;
     c->d_img = img_device;
     c->have_img = true;
     c->have_result = false;
@@ -310,7 +313,7 @@ int ccal_set_intrinsics(ccal_ctx *c, const double intr[CCAL_NINTR]) {
     memcpy(c->intr0, intr, sizeof c->intr0);
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_intr0, c->intr0, sizeof c->intr0, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));
     c->have_intr = true;
     c->have_result = false;
     return CCAL_OK;
@@ -371,6 +374,24 @@ static LmInit make_init(const ccal_ctx *c) {
     return in;
 }
 
+static int finish_init(ccal_ctx *c, bool intr, bool extr) {
+    // read back what the host mirrors and the failure flags of the initialisation kernels
+    double *h_intr = reinterpret_cast<double *>(c->h_flags + 4);   // pinned staging (flags: ints 0..3)
+    HIPCHK(hipMemcpyAsync(h_intr, c->d_intr0, sizeof(double) * 9, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_flags, c->d_fail, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (intr) {
+        if (c->h_flags[1] != 0) return fail(CCAL_E_DEGENERATE, "ccal_init_intrinsics: homography estimation failed");
+        for (int a = 0; a < 9; a++) c->intr0[a] = h_intr[a];
+        for (int a = 0; a < 4; a++)
+            if (!std::isfinite(c->intr0[a])) return fail(CCAL_E_DEGENERATE, "ccal_init_intrinsics: non-finite focal length");
+    }
+    if (extr && c->h_flags[0] != 0)
+        return fail(CCAL_E_DEGENERATE, "ccal_init_extrinsics: pose initialisation failed for " +
+                                           std::to_string(c->h_flags[0]) + " image(s)");
+    return CCAL_OK;
+}
+
 int ccal_init_intrinsics(ccal_ctx *c) {
     if (!c) return fail(CCAL_E_ARG, "ccal_init_intrinsics: ctx == NULL");
     if (!c->have_problem || !c->have_img) return fail(CCAL_E_STATE, "ccal_init_intrinsics: problem/image points not set");
@@ -385,14 +406,7 @@ int ccal_init_intrinsics(ccal_ctx *c) {
     if (rc) return rc;
     const double aspect = (c->flags & CCAL_FIX_ASPECT_RATIO) ? c->aspect : 0.0;
     HIPCHK(launch_init_focal_solve(c->stream, c->d_foc_red, c->d_intr0, c->d_fail, c->width, c->height, aspect));
-    double *h_intr = reinterpret_cast<double *>(c->h_st);   // pinned staging
-    HIPCHK(hipMemcpyAsync(h_intr, c->d_intr0, sizeof(double) * 9, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_flags, c->d_fail, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->h_flags[1] != 0) return fail(CCAL_E_DEGENERATE, "ccal_init_intrinsics: homography estimation failed");
-    for (int a = 0; a < 9; a++) c->intr0[a] = h_intr[a];
-    for (int a = 0; a < 4; a++)
-        if (!std::isfinite(c->intr0[a])) return fail(CCAL_E_DEGENERATE, "ccal_init_intrinsics: non-finite focal length");
+    if (!c->defer_sync && (rc = finish_init(c, true, false)) != CCAL_OK) return rc;
     c->have_intr = true;
     c->have_result = false;
     c->stats.t_init_intr_s = now_s() - t0;
@@ -406,14 +420,11 @@ int ccal_init_extrinsics(ccal_ctx *c) {
     if (!c->planar_z0) return fail(CCAL_E_NONPLANAR, "ccal_init_extrinsics: only planar z = 0 templates are supported");
     HIPCHK(hipSetDevice(c->device));
     const double t0 = now_s();
-    HIPCHK(hipMemsetAsync(c->d_fail, 0, sizeof(int) * 4, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_fail, 0, sizeof(int), c->stream));     // word 0: failed poses (word 1: focal solve)
     HIPCHK(launch_init_extrinsics(c->stream, c->d_obj, c->d_img, c->d_intr0, c->d_ext0, c->d_fail, c->N, c->P));
-    HIPCHK(hipMemcpyAsync(c->h_flags, c->d_fail, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    int rc;
+    if (!c->defer_sync && (rc = finish_init(c, false, true)) != CCAL_OK) return rc;
     c->stats.t_init_extr_s = now_s() - t0;
-    if (c->h_flags[0] != 0)
-        return fail(CCAL_E_DEGENERATE, "ccal_init_extrinsics: pose initialisation failed for " +
-                                           std::to_string(c->h_flags[0]) + " image(s)");
     c->have_ext = true;
     c->have_result = false;
     return CCAL_OK;
@@ -421,7 +432,7 @@ int ccal_init_extrinsics(ccal_ctx *c) {
 
 // ---- A6-A9: global LM ------------------------------------------------------------------
 // (trials << 32) | done, written to pinned host memory by every k_lm_solve that advances the state
-static unsigned long long *progress_word(ccal_ctx *c) { return reinterpret_cast<unsigned long long *>(c->h_flags + 8); }
+static unsigned long long *progress_word(ccal_ctx *c) { return reinterpret_cast<unsigned long long *>(c->h_flags + 32); }
 
 // Wait until the device reports `done` or `target_trials` executed trials.  Spinning on the
 // pinned progress word avoids the wake-up latency of hipStreamSynchronize (tens of microseconds,
@@ -524,11 +535,18 @@ int ccal_lm_run(ccal_ctx *c) {
     c->h_st->done = 0;
     *progress_word(c) = 0ull;
     const bool graphed = c->use_graph && !c->time_sweeps && !sharded(c);
-    if (graphed && c->graph_dirty) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        const int rc = capture_graph(c, &c->g_first);
-        if (rc) return rc;
-        c->graph_dirty = false;
+    if (graphed) {
+        ccal_ctx::GraphKey key;
+        memset(&key, 0, sizeof key);
+        key.obj = c->d_obj; key.img = c->d_img; key.blk = c->d_blk; key.st = c->d_st; key.partials = c->d_partials;
+        key.red = c->d_red; key.trace = c->d_trace; key.intr0 = c->d_intr0; key.ext0 = c->d_ext0;
+        key.N = c->N; key.P = c->P; key.batch = c->lm_batch; key.init = make_init(c);
+        if (c->graph_dirty || !c->g_first || memcmp(&key, &c->graph_key, sizeof key) != 0) {
+            const int rc = capture_graph(c, &c->g_first);
+            if (rc) return rc;
+            c->graph_key = key;
+            c->graph_dirty = false;
+        }
     }
     const double t_enq0 = now_s();
     if (graphed) {
@@ -662,25 +680,43 @@ int ccal_get_init(ccal_ctx *c, double intr[CCAL_NINTR], double *rt_host) {
 }
 
 // ---- one-shot drop-in ------------------------------------------------------------------
+// One context per (host thread, device) is kept alive between ccal_calibrate calls: creating the
+// stream, ~15 device buffers and the launch graph costs far more than a small fit.
+static thread_local ccal_ctx *t_cached[16] = {nullptr};
+
+void ccal_thread_cleanup(void) {
+    for (auto &c : t_cached) { if (c) ccal_destroy(c); c = nullptr; }
+}
+
 int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int32_t width, int32_t height,
                    double aspect, uint32_t flags, int32_t max_iter, double eps, int32_t device, double K4[4],
                    double dist5[5], double *rvecs, double *tvecs, double *rms, int32_t *iters, ccal_stats *stats) {
     if (!obj || !img) return fail(CCAL_E_ARG, "ccal_calibrate: NULL points");
-    ccal_ctx *c = nullptr;
-    int rc = ccal_create(device, &c);
-    if (rc < 0) return rc;
+    if (device < 0 || device >= 16) return fail(CCAL_E_ARG, "ccal_calibrate: bad device index");
+    ccal_ctx *c = t_cached[device];
+    int rc;
+    if (!c) {
+        if ((rc = ccal_create(device, &c)) < 0) return rc;
+        t_cached[device] = c;
+    }
     double intr[9];
     int lm_rc = 0;
+    const bool guess = (flags & CCAL_USE_INTRINSIC_GUESS) != 0;
+    c->defer_sync = true;          // the whole pipeline is enqueued, then checked once
     do {
         if ((rc = ccal_set_problem(c, obj, P, N, width, height, aspect, flags, max_iter, eps)) < 0) break;
         if ((rc = ccal_set_image_points(c, img)) < 0) break;
-        if (flags & CCAL_USE_INTRINSIC_GUESS) {
+        if (guess) {
             if (!K4 || !dist5) { rc = fail(CCAL_E_ARG, "ccal_calibrate: intrinsic guess requested but K4/dist5 NULL"); break; }
             const double g[9] = {K4[0], K4[1], K4[2], K4[3], dist5[0], dist5[1], dist5[2], dist5[3], dist5[4]};
             if ((rc = ccal_set_intrinsics(c, g)) < 0) break;
         } else if ((rc = ccal_init_intrinsics(c)) < 0) break;
         if ((rc = ccal_init_extrinsics(c)) < 0) break;
-        if ((lm_rc = rc = ccal_lm_run(c)) < 0) break;
+        lm_rc = ccal_lm_run(c);
+        const std::string lm_err = g_err;
+        // initialisation failures explain (and outrank) whatever the LM reported on garbage
+        if ((rc = finish_init(c, !guess, true)) < 0) break;
+        if ((rc = lm_rc) < 0) { g_err = lm_err; break; }
         ccal_stats st;
         if ((rc = ccal_get_result(c, intr, rvecs, tvecs, &st)) < 0) break;
         if (K4) memcpy(K4, intr, sizeof(double) * 4);
@@ -690,9 +726,12 @@ int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int
         if (stats) *stats = st;
         rc = lm_rc;
     } while (0);
-    const std::string keep = g_err;
-    ccal_destroy(c);
-    g_err = keep;
+    c->defer_sync = false;
+    if (rc < 0) {                  // leave no half-finished work behind on the cached stream
+        const std::string keep = g_err;
+        (void)hipStreamSynchronize(c->stream);
+        g_err = keep;
+    }
     return rc;
 }
 

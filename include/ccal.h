@@ -154,6 +154,11 @@ int  ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, in
                     int32_t device, double K4[4], double dist5[5], double *rvecs, double *tvecs,
                     double *rms, int32_t *iters, ccal_stats *stats);
 
+/* ccal_calibrate keeps one context per (host thread, device) alive between calls (creating a
+ * stream, the device buffers and the launch graph costs more than a small fit); this frees the
+ * calling thread's cached contexts. */
+void ccal_thread_cleanup(void);
+
 /* ---- point maps and error metrics (src/meta.jl, src/buildcalibrations.jl) ------------ */
 /* real2image[i] (src/meta.jl:27-33,39-44,88): xyz [3,M] -> rowcol [2,M], host arrays. */
 int  ccal_project(ccal_ctx *ctx, const double *xyz, int32_t M, const double f[2], const double c[2],
