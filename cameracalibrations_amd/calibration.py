@@ -8,9 +8,8 @@ Same names, argument meaning and error behaviour as the Julia package
     rectification(c, i)                                                # src/meta.jl:99-103
 
 All arithmetic (fit, maps, error metrics) runs in the HIP library through the C ABI; this
-module only packs arguments.  Corner DETECTION (reference src/detect_fit.jl:5-21, OpenCV
-findChessboardCorners + cornerSubPix) is outside this path: `fit(files, ...)` therefore needs
-a `detector` callable and raises without one.
+module only packs arguments.  Corner detection (reference src/detect_fit.jl:5-21) uses the device
+detector of csrc/ccal_detect.hip unless a `detector` callable is passed to `fit`.
 """
 import re
 from dataclasses import dataclass, field
@@ -143,12 +142,20 @@ def fit(files, n_corners, checker_size, aspect=1, with_distortion=True, inverse_
         detector: Optional[Callable] = None, sz=None, rng=None, device=0):
     """fit(files, n_corners, checker_size; aspect, with_distortion, inverse_samples, with_plot)
     (src/buildcalibrations.jl:12-26).  `detector(file, n_corners) -> (P,2) corners or None`
-    stands in for `_detect_corners` (src/detect_fit.jl:5-21), which stays with OpenCV."""
+    overrides the built-in device detector that stands in for `_detect_corners`
+    (src/detect_fit.jl:5-21)."""
     if with_plot:
         raise NotImplementedError("plotting (src/plot_calibration.jl) is outside the accelerated path")
     if detector is None:
-        raise NotImplementedError("corner detection (src/detect_fit.jl:5-21) is outside the accelerated path: "
-                                  "pass detector=..., or call fit_corners with detected corners")
+        from .detect import detect_corners, load_gray      # device detector (csrc/ccal_detect.hip)
+        cache = {}
+
+        def detector(f, nc):
+            img = cache.setdefault(f, load_gray(f))
+            c = detect_corners(img, nc)
+            return None if c is None else c.transpose(1, 0, 2).reshape(-1, 2)   # first dim fastest
+        if sz is None:
+            sz = load_gray(next(iter(files))).shape       # size(FileIO.load(first(files))), src/detect_fit.jl:64
     seen, uniq = set(), []
     for f in files:                                      # unique(files), src/buildcalibrations.jl:14
         if f not in seen:

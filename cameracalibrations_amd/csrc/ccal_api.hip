@@ -17,6 +17,7 @@
 
 #include "../../include/ccal.h"
 #include "ccal_comm.hpp"
+#include "ccal_detect.hpp"
 #include "ccal_kernels.hpp"
 #include "ccal_state.hpp"
 
@@ -82,6 +83,7 @@ struct ccal_ctx {
     void *ar_user = nullptr;
     int world = 1, rank = 0;
     Comm *comm = nullptr;              // native RCCL communicator (ccal_comm_init_rank)
+    Detector *detector = nullptr;      // corner detector buffers (ccal_detect_corners)
     int64_t n_global = 0;
     int lm_batch = 8;
     // optional per-sweep event timing
@@ -173,6 +175,7 @@ void ccal_destroy(ccal_ctx *c) {
     (void)hipHostFree(c->h_st); (void)hipHostFree(c->h_flags);
     for (auto &e : c->ev) (void)hipEventDestroy(e);
     delete c->comm;
+    delete c->detector;
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -812,6 +815,25 @@ int ccal_errors(ccal_ctx *c, int32_t N, int32_t n1, int32_t n2, const double *ob
     out[1] = std::sqrt(sums[1] / n);
     out[2] = std::sqrt(sums[2] / ((double)(n1 - 1) * (n2 - 1)) / N);
     out[3] = (S > 0 && inv_pts) ? std::sqrt(sums[3] / S / N) : 0.0;
+    return CCAL_OK;
+}
+
+// ---- corner detection ----------------------------------------
+int ccal_detect_corners(ccal_ctx *c, const uint8_t *gray, int32_t rows, int32_t cols, int64_t stride_row,
+                        int64_t stride_col, int32_t n1, int32_t n2, double *corners, int32_t *found,
+                        double *stage_out) {
+    if (!c || !gray || !corners || !found) return fail(CCAL_E_ARG, "ccal_detect_corners: NULL argument");
+    if (rows < 32 || cols < 32 || n1 < 2 || n2 < 2 || (int64_t)n1 * n2 > Detector::MAX_PEAKS)
+        return fail(CCAL_E_ARG, "ccal_detect_corners: bad image or board size");
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->detector) c->detector = new Detector();
+    std::string err;
+    int f = 0;
+    const int rc = c->detector->detect(c->stream, gray, rows, cols, stride_row, stride_col, n1, n2, corners, &f,
+                                       stage_out, err);
+    if (rc == -1) return fail(CCAL_E_ARG, "ccal_detect_corners: " + err);
+    if (rc < 0) return fail(CCAL_E_DEVICE, err);
+    *found = f;
     return CCAL_OK;
 }
 

@@ -176,6 +176,18 @@ int  ccal_errors(ccal_ctx *ctx, int32_t N, int32_t n1, int32_t n2, const double 
                  const double *rvecs, const double *tvecs, double checker_size, int32_t S,
                  const double *inv_pts, double out[4]);
 
+/* ---- corner detection (next row after the fit: SURVEY.md 8f) -------------------------- */
+/* Replaces `_detect_corners` (src/detect_fit.jl:5-21: OpenCV findChessboardCorners + cornerSubPix)
+ * for one 8-bit gray image.  Element (row, col) of the Julia image is gray[row * stride_row +
+ * col * stride_col] -- Julia hands OpenCV the column-major matrix (stride_row = 1, stride_col =
+ * rows; src/detect_fit.jl:7), numpy uses (cols, 1).  corners [2, n1*n2] Float64 = RowCol (row, col),
+ * 0-based pixel centres, first n_corners dimension fastest, in OpenCV's corner order; *found = 0
+ * is the reference's `missing`.  stage_out: NULL, or 2*rows*cols doubles (blurred image, response)
+ * for stage-wise tests. */
+int  ccal_detect_corners(ccal_ctx *ctx, const uint8_t *gray, int32_t rows, int32_t cols, int64_t stride_row,
+                         int64_t stride_col, int32_t n1, int32_t n2, double *corners, int32_t *found,
+                         double *stage_out);
+
 /* ---- diagnostics (stage-wise parity tests; not part of the reference surface) -------- */
 /* per-image 16x16 Gram matrices [Je|Ji|e]^T[Je|Ji|e] at the given point -> G [256,N] host */
 int  ccal_debug_image_grams(ccal_ctx *ctx, const double intr[CCAL_NINTR], const double *rt_host,

@@ -1,0 +1,114 @@
+"""Corner detection (next row after the fit).
+
+The reference's bar for this step is its own test suite: every detected corner within 1 px of the
+analytic position on synthetic boards (reference test/runtests.jl:6-43) and within 1 px of
+test/example/corners.json on the six example PNGs (test/runtests.jl:53-65), in OpenCV's corner
+order.  CPU tests hold the oracle (oracle/detect_oracle.py) to that bar; GPU tests hold the HIP
+detector to the same bar, to the oracle (1e-6 px), and run the reference's end-to-end
+"Full calibration" test (test/runtests.jl:68-85) from the PNG files.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import detect_oracle as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PNG = os.path.join(ROOT, "tests", "golden", "example_png")
+
+
+def _example():
+    from PIL import Image
+    ex = json.load(open(os.path.join(ROOT, "tests", "golden", "example_corners.json")))
+    imgs = [np.asarray(Image.open(os.path.join(PNG, f))) for f in ex["files"]]
+    return ex, imgs
+
+
+def test_oracle_real_images_within_one_pixel():
+    ex, imgs = _example()
+    for f, im, tgt in zip(ex["files"], imgs, ex["corners"]):
+        res = D.detect_corners(im, tuple(ex["n_corners"]))
+        assert res is not None, f
+        assert np.linalg.norm(res - np.array(tgt, dtype=float), axis=1).max() < 1, f     # runtests.jl:63
+
+
+@pytest.mark.parametrize("w,h,ratio", [(13, 14, 95), (14, 15, 100)])
+def test_oracle_synthetic_boards(w, h, ratio):
+    xys, img = D.generate_checkerboard((w, h), ratio)
+    res = D.detect_corners(img, (w, h))
+    assert res is not None and np.linalg.norm(res - xys, axis=1).max() < 1                # runtests.jl:26,40
+
+
+def test_oracle_rejects_wrong_board():
+    ex, imgs = _example()
+    assert D.detect_corners(imgs[0], (7, 9)) is None            # `missing` (src/detect_fit.jl:16)
+    assert D.detect_corners(np.full((200, 200), 128, dtype=np.uint8), (5, 8)) is None
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+def test_gpu_stages_match_oracle():
+    from cameracalibrations_amd.detect import detect_corners
+    ex, imgs = _example()
+    im = imgs[2]
+    res, stage = detect_corners(im, tuple(ex["n_corners"]), stages=True)
+    g = D.blur(im.astype(np.float64))
+    R = D.chess_response(g)
+    assert np.abs(stage[0] - g).max() < 1e-10
+    assert np.abs(stage[1] - R).max() < 1e-9
+    want = D.detect_corners(im, tuple(ex["n_corners"]))
+    assert np.abs(res.transpose(1, 0, 2).reshape(-1, 2) - want).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_real_images_reference_bar():
+    from cameracalibrations_amd.detect import detect_corners
+    ex, imgs = _example()
+    nc = tuple(ex["n_corners"])
+    for f, im, tgt in zip(ex["files"], imgs, ex["corners"]):
+        res = detect_corners(im, nc)
+        assert res is not None and res.shape == (nc[0], nc[1], 2), f
+        flat = res.transpose(1, 0, 2).reshape(-1, 2)                                       # vec(corners)
+        assert np.linalg.norm(flat - np.array(tgt, dtype=float), axis=1).max() < 1, f     # runtests.jl:63
+        assert np.abs(flat - D.detect_corners(im, nc)).max() < 1e-6, f
+        # Julia hands OpenCV the column-major matrix: same image, transposed strides
+        jl = np.asfortranarray(im)
+        assert np.array_equal(detect_corners(jl, nc), res)
+    assert detect_corners(imgs[0], (7, 9)) is None
+
+
+@pytest.mark.gpu
+def test_gpu_synthetic_boards_reference_loop():
+    """for w in 13:15, h in 13:15, ratio in 95:100 if isodd(w) != isodd(h)   (runtests.jl:36-43)"""
+    from cameracalibrations_amd.detect import detect_corners
+    n = 0
+    for w in (13, 14, 15):
+        for h in (13, 14, 15):
+            if (w % 2) == (h % 2):
+                continue
+            for ratio in range(95, 101):
+                xys, img = D.generate_checkerboard((w, h), ratio)
+                res = detect_corners(img.astype(np.uint8), (w, h))
+                assert res is not None, (w, h, ratio)
+                flat = res.transpose(1, 0, 2).reshape(-1, 2)
+                assert np.linalg.norm(flat - xys, axis=1).max() < 1, (w, h, ratio)
+                n += 1
+    assert n == 24
+
+
+@pytest.mark.gpu
+def test_gpu_full_calibration_from_files():
+    """The reference's "Full calibration" testset (test/runtests.jl:68-85), files in, everything on
+    the device: detection, fit, maps, error metrics."""
+    import cameracalibrations_amd as cc
+    files = sorted(os.path.join(PNG, f) for f in os.listdir(PNG) if f.endswith(".png"))
+    c, eps = cc.fit(files, (5, 8), 1, rng=np.random.default_rng(3))
+    assert eps["n"] == 6
+    assert all(eps[k] < 1 for k in ("reprojection", "projection", "distance", "inverse")), eps
+    f = cc.rectification(c, 1)
+    i = cc.RowCol(1, 2)
+    assert np.array_equal(f(i), c(i, 1)[[0, 1]])
+    # sub-pixel corners give a far better fit than the integer-rounded fixture (0.469 px)
+    assert eps["reprojection"] < 0.35   # sub-pixel corners: 0.27 px, against 0.469 px from the integer-rounded fixture

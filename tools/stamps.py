@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "cameracalibrations_amd", "csrc")
 OUT = "/tmp/libccal_hip_stamps.so"
-srcs = [os.path.join(CSRC, f) for f in ("ccal_lm.hip", "ccal_init.hip", "ccal_maps.hip", "ccal_comm.hip", "ccal_api.hip")]
+srcs = [os.path.join(CSRC, f) for f in ("ccal_lm.hip", "ccal_init.hip", "ccal_maps.hip", "ccal_comm.hip", "ccal_detect.hip", "ccal_api.hip")]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                        "-DCCAL_STAMPS", "-o", OUT, *srcs, "-ldl"])
 from cameracalibrations_amd import _ffi as F  # noqa: E402
