@@ -87,6 +87,9 @@ SIGNATURES = {
     "ccal_unproject": (C.c_int, [C.c_void_p, _dp, C.c_int32, _dp, _dp, C.c_double, _dp, _dp, C.c_double, _dp]),
     "ccal_errors": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, C.c_double, _dp, _dp,
                               C.c_double, C.c_int32, _dp, _dp]),
+    "ccal_rectify_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
+                                     _dp, _dp, C.c_double, _dp, _dp, C.c_double, C.c_double, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_double, C.c_void_p]),
     "ccal_detect_corners": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
                                       C.c_int32, _dp, C.POINTER(C.c_int32), _dp]),
     "ccal_debug_image_grams": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),

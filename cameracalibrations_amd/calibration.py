@@ -12,6 +12,7 @@ module only packs arguments.  Corner detection (reference src/detect_fit.jl:5-21
 detector of csrc/ccal_detect.hip unless a `detector` callable is passed to `fit`.
 """
 import re
+import threading
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence
 
@@ -30,14 +31,19 @@ def XYZ(x, y, z):
     return np.array([x, y, z], dtype=np.float64)
 
 
+_tls = threading.local()
+
+
 def _shared_solver(device=0):
-    s = _shared_solver.cache.get(device)
+    """One device context per host thread (a `ccal_ctx` serves one thread at a time; the reference's
+    FFI wrapper is exercised under Threads.@threads, test/runtests.jl:45-51)."""
+    cache = getattr(_tls, "solvers", None)
+    if cache is None:
+        cache = _tls.solvers = {}
+    s = cache.get(device)
     if s is None:
-        s = _shared_solver.cache[device] = _solver.Solver(device)
+        s = cache[device] = _solver.Solver(device)
     return s
-
-
-_shared_solver.cache = {}
 
 
 @dataclass
@@ -144,8 +150,6 @@ def fit(files, n_corners, checker_size, aspect=1, with_distortion=True, inverse_
     (src/buildcalibrations.jl:12-26).  `detector(file, n_corners) -> (P,2) corners or None`
     overrides the built-in device detector that stands in for `_detect_corners`
     (src/detect_fit.jl:5-21)."""
-    if with_plot:
-        raise NotImplementedError("plotting (src/plot_calibration.jl) is outside the accelerated path")
     if detector is None:
         from .detect import detect_corners, load_gray      # device detector (csrc/ccal_detect.hip)
         cache = {}
@@ -165,5 +169,9 @@ def fit(files, n_corners, checker_size, aspect=1, with_distortion=True, inverse_
     found = [(f, m) for f, m in found if m is not None]  # skipmissing, src/detect_fit.jl:65
     if sz is None:
         raise ValueError("sz (size of the first image, (rows, cols)) is required")
-    return fit_corners([m for _, m in found], n_corners, checker_size, sz, [f for f, _ in found], aspect,
-                       with_distortion, inverse_samples, rng, device)
+    c, eps = fit_corners([m for _, m in found], n_corners, checker_size, sz, [f for f, _ in found], aspect,
+                         with_distortion, inverse_samples, rng, device)
+    if with_plot:                                        # src/buildcalibrations.jl:22-24
+        from .plot import plot
+        plot(c, [m for _, m in found], n_corners, checker_size, sz)
+    return c, eps

@@ -818,6 +818,33 @@ int ccal_errors(ccal_ctx *c, int32_t N, int32_t n1, int32_t n2, const double *ob
     return CCAL_OK;
 }
 
+// ---- rectified image -----------------------------------------
+int ccal_rectify_image(ccal_ctx *c, const uint8_t *img, int32_t rows, int32_t cols, int32_t channels, int64_t stride_row,
+                       int64_t stride_col, int64_t stride_ch, const double f[2], const double cc[2], double k,
+                       const double rvec[3], const double tvec[3], double checker_size, double ratio, int32_t a0,
+                       int32_t b0, int32_t out_rows, int32_t out_cols, double index_offset, uint8_t *out) {
+    if (!c || !img || !out || !f || !cc || !rvec || !tvec) return fail(CCAL_E_ARG, "ccal_rectify_image: NULL argument");
+    if (rows < 1 || cols < 1 || channels < 1 || channels > 4 || out_rows < 1 || out_cols < 1 || !(ratio > 0.0) ||
+        !(checker_size != 0.0) || stride_row < 1 || stride_col < 1 || stride_ch < 1)
+        return fail(CCAL_E_ARG, "ccal_rectify_image: bad sizes / strides");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t span = (size_t)((rows - 1) * stride_row + (cols - 1) * stride_col + (channels - 1) * stride_ch + 1);
+    const size_t out_bytes = (size_t)out_rows * out_cols * channels;
+    DevBuf din, dout, dpar;
+    HIPCHK(hipMalloc(&din.p, span));
+    HIPCHK(hipMalloc(&dout.p, out_bytes));
+    HIPCHK(hipMalloc(&dpar.p, sizeof(double) * 16));
+    const double par[16] = {f[0], f[1], cc[0], cc[1], k, rvec[0], rvec[1], rvec[2], tvec[0], tvec[1], tvec[2],
+                            checker_size, ratio, index_offset, 0, 0};
+    HIPCHK(hipMemcpyAsync(din.p, img, span, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(dpar.p, par, sizeof par, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_rectify(c->stream, (const uint8_t *)din.p, rows, cols, channels, stride_row, stride_col, stride_ch, a0, b0,
+                          out_rows, out_cols, (const double *)dpar.p, (uint8_t *)dout.p));
+    HIPCHK(hipMemcpyAsync(out, dout.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CCAL_OK;
+}
+
 // ---- corner detection ----------------------------------------
 int ccal_detect_corners(ccal_ctx *c, const uint8_t *gray, int32_t rows, int32_t cols, int64_t stride_row,
                         int64_t stride_col, int32_t n1, int32_t n2, double *corners, int32_t *found,

@@ -42,6 +42,8 @@ hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const fl
 // ccal_maps.hip -- RowCol <-> XYZ maps and the four RMS metrics
 hipError_t launch_map_forward(hipStream_t stream, const double *xyz, double *rc, int M, const double *par);
 hipError_t launch_map_inverse(hipStream_t stream, const double *rc, double *xyz, int M, const double *par);
+hipError_t launch_rectify(hipStream_t stream, const uint8_t *img, int rows, int cols, int ch, long long sr, long long sc,
+                          long long sk, int a0, int b0, int out_rows, int out_cols, const double *par, uint8_t *out);
 hipError_t launch_errors(hipStream_t stream, const double *obj, const double *img, const double *par,
                          const double *rt, const double *inv_pts, double *partials, int N, int n1, int n2, int S);
 

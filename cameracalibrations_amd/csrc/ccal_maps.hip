@@ -7,6 +7,8 @@
 // All FP64; one lane per point, coalesced [3,M] / [2,M] streams.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 #include "ccal_kernels.hpp"
 #include "ccal_math.hpp"
 
@@ -121,6 +123,46 @@ __global__ __launch_bounds__(64) void k_errors_reduce(const double *__restrict__
     double s = 0.0;
     for (int i = 0; i < N; i++) s += partials[(size_t)4 * i + j];
     out[j] = s;
+}
+
+// Rectified view of one image (reference src/plot_calibration.jl:15-22,40: `warp(img, tform, axs)` with
+// tform = real2image[i] o push(.,0) o inv(ratio I)): output pixel (a, b) of the axes a0.., b0.. shows
+// the image at real2image((a, b, 0) / ratio), bilinear, `fill` outside.  par = f0 f1 c0 c1 k r t(6)
+// checker_size ratio index_offset.  One lane per output pixel and channel triple.
+__global__ __launch_bounds__(256) void k_rectify(const uint8_t *__restrict__ img, int rows, int cols, int ch,
+                                                  long long sr, long long sc, long long sk, int a0, int b0, int out_rows,
+                                                  int out_cols, const double *__restrict__ par, uint8_t *__restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= out_cols) return;
+    const double f[2] = {par[0], par[1]}, c[2] = {par[2], par[3]};
+    const double r[3] = {par[5], par[6], par[7]}, t[3] = {par[8], par[9], par[10]};
+    const double ratio = par[12], off = par[13];
+    double R[9];
+    rodrigues_R(r, R);
+    const double w[3] = {(double)(a0 + i) / ratio, (double)(b0 + j) / ratio, 0.0};
+    double rc[2];
+    map_forward(w, f, c, par[4], R, t, 1.0 / par[11], rc);
+    const double y = rc[0] - off, x = rc[1] - off;            // 0-based (row, col) into the array
+    const bool inside = y >= 0.0 && y <= (double)(rows - 1) && x >= 0.0 && x <= (double)(cols - 1);
+    const int y0 = inside ? (int)floor(y) : 0, x0 = inside ? (int)floor(x) : 0;
+    const int y1 = min(y0 + 1, rows - 1), x1 = min(x0 + 1, cols - 1);
+    const double fy = y - y0, fx = x - x0;
+    for (int k = 0; k < ch; k++) {
+        double v = 0.0;
+        if (inside) {
+            const double p00 = img[y0 * sr + x0 * sc + k * sk], p01 = img[y0 * sr + x1 * sc + k * sk];
+            const double p10 = img[y1 * sr + x0 * sc + k * sk], p11 = img[y1 * sr + x1 * sc + k * sk];
+            v = (1 - fy) * ((1 - fx) * p00 + fx * p01) + fy * ((1 - fx) * p10 + fx * p11);
+        }
+        out[((size_t)i * out_cols + j) * ch + k] = (uint8_t)fmin(fmax(floor(v + 0.5), 0.0), 255.0);
+    }
+}
+
+hipError_t launch_rectify(hipStream_t stream, const uint8_t *img, int rows, int cols, int ch, long long sr, long long sc,
+                          long long sk, int a0, int b0, int out_rows, int out_cols, const double *par, uint8_t *out) {
+    hipLaunchKernelGGL(k_rectify, dim3((out_cols + 255) / 256, out_rows), dim3(256), 0, stream, img, rows, cols, ch, sr, sc,
+                       sk, a0, b0, out_rows, out_cols, par, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_map_forward(hipStream_t stream, const double *xyz, double *rc, int M, const double *par) {

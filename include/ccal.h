@@ -176,6 +176,18 @@ int  ccal_errors(ccal_ctx *ctx, int32_t N, int32_t n1, int32_t n2, const double 
                  const double *rvecs, const double *tvecs, double checker_size, int32_t S,
                  const double *inv_pts, double out[4]);
 
+/* ---- rectified image -------------------------------------------- */
+/* `warp(img, tform, axs)` of src/plot_calibration.jl:15-22,40 with tform = real2image[i] o push(.,0) o
+ * inv(ratio I): out[a - a0, b - b0, :] = img at real2image((a, b, 0) / ratio) - index_offset, bilinear,
+ * 0 outside.  img: 8-bit, element (row, col, ch) at img[row*stride_row + col*stride_col + ch*stride_ch];
+ * out: [out_rows, out_cols, channels] C order.  index_offset = 1 reproduces the reference, which uses
+ * the 0-based RowCol of the fit as 1-based Julia indices. */
+int  ccal_rectify_image(ccal_ctx *ctx, const uint8_t *img, int32_t rows, int32_t cols, int32_t channels,
+                        int64_t stride_row, int64_t stride_col, int64_t stride_ch, const double f[2],
+                        const double c[2], double k, const double rvec[3], const double tvec[3],
+                        double checker_size, double ratio, int32_t a0, int32_t b0, int32_t out_rows,
+                        int32_t out_cols, double index_offset, uint8_t *out);
+
 /* ---- corner detection (next row after the fit: SURVEY.md 8f) -------------------------- */
 /* Replaces `_detect_corners` (src/detect_fit.jl:5-21: OpenCV findChessboardCorners + cornerSubPix)
  * for one 8-bit gray image.  Element (row, col) of the Julia image is gray[row * stride_row +

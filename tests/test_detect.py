@@ -112,3 +112,19 @@ def test_gpu_full_calibration_from_files():
     assert np.array_equal(f(i), c(i, 1)[[0, 1]])
     # sub-pixel corners give a far better fit than the integer-rounded fixture (0.469 px)
     assert eps["reprojection"] < 0.35   # sub-pixel corners: 0.27 px, against 0.469 px from the integer-rounded fixture
+
+
+@pytest.mark.gpu
+def test_gpu_detection_threaded():
+    """runtests.jl:45-51: the detection wrapper is used under Threads.@threads -- one device context
+    per host thread, identical results."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from cameracalibrations_amd.detect import detect_corners
+    ex, imgs = _example()
+    nc = tuple(ex["n_corners"])
+    serial = [detect_corners(im, nc) for im in imgs]
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        threaded = list(pool.map(lambda im: detect_corners(im, nc), imgs * 4))
+    for k, res in enumerate(threaded):
+        assert np.array_equal(res, serial[k % len(imgs)])
