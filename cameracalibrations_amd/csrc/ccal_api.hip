@@ -483,7 +483,8 @@ static int enqueue_trial(ccal_ctx *c, hipStream_t stream, int k, bool final_only
         if (sharded(c)) {
             // 16 workgroups condense the partials (one would be bound by a single CU's ~64 GB/s); the
             // 16 rows (8.7 KB, still latency-bound) are summed across GPUs and added up in the prologue
-            const int rows = nb < SHARD_ROWS ? nb : SHARD_ROWS;
+            // (always 16: the message size must not depend on the local shard size; surplus rows are zero)
+            const int rows = SHARD_ROWS;
             HIPCHK(launch_lm_reduce(stream, prev, nb, c->d_red, rows));
             const int rc = run_allreduce(c, c->d_red, NRED * rows);
             if (rc) return rc;

@@ -366,3 +366,55 @@ def test_non_finite_input_is_reported():
         with pytest.raises(F.CcalError) as e:
             s.calibrate()
         assert e.value.code in (F.E_NONFINITE, F.E_DEGENERATE)
+
+
+def _two_rank_worker(rank, world, port, n_total, out):
+    import torch
+    import torch.distributed as dist
+    from cameracalibrations_amd.distributed import TorchAllReduce, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)                               # both ranks share the one GPU of the test box
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        wl = syn.named_workload("C2", n_images=n_total)
+        lo, hi = shard_range(n_total, world, rank)
+        with Solver(0, stream=torch.cuda.current_stream().cuda_stream) as s:
+            s.set_problem(wl.obj, hi - lo, wl.image_size, aspect=wl.aspect, flags=wl.flags)
+            s.set_image_points(torch.from_numpy(wl.img[lo:hi]).cuda())
+            s.set_allreduce(TorchAllReduce(), world, rank, n_total)
+            st, r = s.calibrate()
+        out[rank] = dict(status=st, lo=lo, hi=hi, intr=r["intr"].tolist(), rvecs=r["rvecs"].tolist(),
+                         tvecs=r["tvecs"].tolist(), rms=r["rms"], iters=r["iters"], sweeps=r["sweeps"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_fit_two_ranks_on_one_gpu():
+    """The multi-GPU algorithm end to end with REAL kernels: two processes share the one GPU, each
+    holds half of the images, the reduced system is all-reduced through the torch.distributed hook
+    (gloo here; the driver's multi-GPU run uses RCCL).  The joint fit must equal the single-process
+    fit of all images: same LM trajectory, parameters to 1e-9 (only the summation order differs)."""
+    import socket
+
+    import torch.multiprocessing as mp
+    n_total = 41
+    wl = syn.named_workload("C2", n_images=n_total)
+    with _solver(wl, REF) as s:
+        _, base = s.calibrate()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_two_rank_worker, args=(2, port, n_total, out), nprocs=2, join=True)
+    assert set(out.keys()) == {0, 1}
+    a, b = out[0], out[1]
+    assert a["intr"] == b["intr"] and a["rms"] == b["rms"] and a["iters"] == b["iters"]     # replicated state
+    assert a["iters"] == base["iters"] and a["sweeps"] == base["sweeps"]
+    assert abs(a["rms"] - base["rms"]) < 1e-12
+    assert np.abs(np.array(a["intr"]) - base["intr"]).max() < 1e-9 * base["intr"][1]
+    rv = np.vstack([np.array(a["rvecs"]), np.array(b["rvecs"])])
+    tv = np.vstack([np.array(a["tvecs"]), np.array(b["tvecs"])])
+    assert (a["lo"], a["hi"], b["lo"], b["hi"]) == (0, 21, 21, 41)
+    assert np.abs(rv - base["rvecs"]).max() < 1e-10 and np.abs(tv - base["tvecs"]).max() < 1e-9
