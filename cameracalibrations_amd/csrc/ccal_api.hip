@@ -24,7 +24,7 @@
 using namespace ccal;
 
 #ifdef CCAL_STAMPS
-namespace ccal { hipError_t debug_read_stamps(unsigned long long *out); }
+namespace ccal { hipError_t debug_read_stamps(unsigned long long *out); hipError_t debug_read_init_stamps(unsigned long long *out); }
 #endif
 
 // prologue reduction: every workgroup sums the previous partials itself while they are few; beyond
@@ -918,6 +918,11 @@ int ccal_time_sweep(ccal_ctx *c, int32_t reps, double *avg_us) {
 }
 
 #ifdef CCAL_STAMPS
+int ccal_debug_init_stamps(unsigned long long *out) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(ccal::debug_read_init_stamps(out));
+    return CCAL_OK;
+}
 int ccal_debug_stamps(unsigned long long *out) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(ccal::debug_read_stamps(out));

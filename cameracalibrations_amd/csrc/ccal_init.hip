@@ -20,6 +20,25 @@
 
 namespace ccal {
 
+#ifdef CCAL_STAMPS
+__device__ unsigned long long g_init_stamps[16];
+#define ISTAMP(i)                                                                             \
+    do {                                                                                      \
+        if (blockIdx.x == 7 && threadIdx.x == 0) {                                            \
+            unsigned long long t_;                                                            \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            g_init_stamps[i] = t_;                                                            \
+        }                                                                                     \
+    } while (0)
+#define ICOUNT(i, v) do { if (blockIdx.x == 7 && threadIdx.x == 0) g_init_stamps[i] = (unsigned long long)(v); } while (0)
+hipError_t debug_read_init_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_init_stamps), sizeof(unsigned long long) * 16);
+}
+#else
+#define ISTAMP(i) do { } while (0)
+#define ICOUNT(i, v) do { } while (0)
+#endif
+
 constexpr double DBL_EPS = 2.220446049250313e-16;
 constexpr double FLT_EPS = 1.1920928955078125e-07;
 
@@ -89,13 +108,13 @@ __device__ double homog_error(const Pts &pts, int P, int lane, const double h[8]
             m = fmax(m, fmax(fabs(eu), fabs(ev)));
         }
     }
-#pragma unroll
-    for (int k = 32; k > 0; k >>= 1) m = fmax(m, __shfl_xor(m, k, 64));
-    rmax = m;
+    rmax = wave_max(m);
     return wave_sum(s);
 }
 
-// A (8x8 packed lower) = J^T J, v = J^T r, S = r^T r at h, via the MFMA Gram (columns 0-7 J, 8 r)
+// A (8x8 packed lower) = J^T J, v = J^T r, S = r^T r at h.  The u-row of a correspondence touches
+// only parameters {0,1,2,6,7} and the v-row only {3,4,5,6,7}, so both fit the packed 8-column Gram
+// (ccal_wave.hpp): u-row -> [J0 J1 J2 J6 J7 eu 0 0], v-row -> [J3 J4 J5 J6 J7 ev 0 0].
 template <class Pts>
 __device__ void homog_normal_eq(const Pts &pts, int P, int lane, const double h[8], double *tile, double *Gs,
                                 double A[36], double v[8], double &S) {
@@ -106,25 +125,33 @@ __device__ void homog_normal_eq(const Pts &pts, int P, int lane, const double h[
         double Mx, My, mx, my, eu, ev, ww, xi, yi;
         pts.get(valid ? p : P - 1, Mx, My, mx, my);
         homog_point(h, Mx, My, mx, my, eu, ev, ww, xi, yi);
-        double mu[16], mv[16];
-#pragma unroll
-        for (int c = 0; c < 16; c++) { mu[c] = 0.0; mv[c] = 0.0; }
-        mu[0] = Mx * ww; mu[1] = My * ww; mu[2] = ww; mu[6] = -Mx * ww * xi; mu[7] = -My * ww * xi; mu[8] = eu;
-        mv[3] = Mx * ww; mv[4] = My * ww; mv[5] = ww; mv[6] = -Mx * ww * yi; mv[7] = -My * ww * yi; mv[8] = ev;
-        tile_store_rows(tile, lane, mu, mv, valid);
+        const double ru[8] = {Mx * ww, My * ww, ww, -Mx * ww * xi, -My * ww * xi, eu, 0.0, 0.0};
+        const double rv[8] = {Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi, ev, 0.0, 0.0};
+        tile8_store_rows(tile, lane, ru, rv, valid);
         __syncthreads();
-        tile_gram(tile, lane, min(64, P - c0), acc0, acc1);
+        tile8_gram(tile, lane, min(64, P - c0), acc0, acc1);
         __syncthreads();
     }
     gram_to_lds(Gs, lane, acc0, acc1);
     __syncthreads();
+    // packed index k of parameter a inside the u-block (0-2, 6->3, 7->4) and the v-block (3-5 -> 0-2, 6->3, 7->4)
 #pragma unroll
     for (int a = 0; a < 8; a++) {
+        const int ua = a < 3 ? a : (a >= 6 ? a - 3 : -1), va = (a >= 3 && a < 6) ? a - 3 : (a >= 6 ? a - 3 : -1);
 #pragma unroll
-        for (int b = 0; b <= a; b++) A[tri(a, b)] = Gs[a * 16 + b];
-        v[a] = Gs[a * 16 + 8];
+        for (int b = 0; b <= a; b++) {
+            const int ub = b < 3 ? b : (b >= 6 ? b - 3 : -1), vb = (b >= 3 && b < 6) ? b - 3 : (b >= 6 ? b - 3 : -1);
+            double g = 0.0;
+            if (ua >= 0 && ub >= 0) g += Gs[ua * 16 + ub];
+            if (va >= 0 && vb >= 0) g += Gs[(8 + va) * 16 + 8 + vb];
+            A[tri(a, b)] = g;
+        }
+        double w = 0.0;
+        if (ua >= 0) w += Gs[ua * 16 + 5];
+        if (va >= 0) w += Gs[(8 + va) * 16 + 13];
+        v[a] = w;
     }
-    S = Gs[8 * 16 + 8];
+    S = Gs[5 * 16 + 5] + Gs[13 * 16 + 13];
     __syncthreads();
 }
 
@@ -201,7 +228,7 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *tile, doub
             rmax = rdmax;
         }
         iter++;
-        if (!(iter < 10 && dmax >= FLT_EPS && rmax >= FLT_EPS)) break;
+        if (!(iter < 10 && dmax >= FLT_EPS && rmax >= FLT_EPS)) { ICOUNT(7, iter); break; }
     }
 }
 
@@ -232,7 +259,8 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *tile, d
     if (fabs(sm0) < DBL_EPS || fabs(sm1) < DBL_EPS || fabs(sM0) < DBL_EPS || fabs(sM1) < DBL_EPS) return false;
     sm0 = P / sm0; sm1 = P / sm1; sM0 = P / sM0; sM1 = P / sM1;
 
-    // LtL = sum Lx Lx^T + Ly Ly^T through the MFMA Gram (9 of 16 columns used)
+    // LtL = sum Lx Lx^T + Ly Ly^T through the packed 8-column MFMA Gram: Lx touches entries
+    // {0,1,2,6,7,8} of h and Ly {3,4,5,6,7,8} -> [X Y 1 -xX -xY -x 0 0] and [X Y 1 -yX -yY -y 0 0]
     d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     for (int c0 = 0; c0 < P; c0 += 64) {
         const int p = c0 + lane;
@@ -241,14 +269,11 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *tile, d
         pts.get(valid ? p : P - 1, Mx, My, mx, my);
         const double x = (mx - cm0) * sm0, y = (my - cm1) * sm1;
         const double X = (Mx - cM0) * sM0, Y = (My - cM1) * sM1;
-        double mu[16], mv[16];
-#pragma unroll
-        for (int c = 0; c < 16; c++) { mu[c] = 0.0; mv[c] = 0.0; }
-        mu[0] = X; mu[1] = Y; mu[2] = 1.0; mu[6] = -x * X; mu[7] = -x * Y; mu[8] = -x;
-        mv[3] = X; mv[4] = Y; mv[5] = 1.0; mv[6] = -y * X; mv[7] = -y * Y; mv[8] = -y;
-        tile_store_rows(tile, lane, mu, mv, valid);
+        const double ru[8] = {X, Y, 1.0, -x * X, -x * Y, -x, 0.0, 0.0};
+        const double rv[8] = {X, Y, 1.0, -y * X, -y * Y, -y, 0.0, 0.0};
+        tile8_store_rows(tile, lane, ru, rv, valid);
         __syncthreads();
-        tile_gram(tile, lane, min(64, P - c0), acc0, acc1);
+        tile8_gram(tile, lane, min(64, P - c0), acc0, acc1);
         __syncthreads();
     }
     gram_to_lds(Gs, lane, acc0, acc1);
@@ -256,8 +281,15 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *tile, d
     double A[45], trace = 0.0;
 #pragma unroll
     for (int a = 0; a < 9; a++) {
+        const int ua = a < 3 ? a : (a >= 6 ? a - 3 : -1), va = (a >= 3 && a < 6) ? a - 3 : (a >= 6 ? a - 3 : -1);
 #pragma unroll
-        for (int b = 0; b <= a; b++) A[tri(a, b)] = Gs[a * 16 + b];
+        for (int b = 0; b <= a; b++) {
+            const int ub = b < 3 ? b : (b >= 6 ? b - 3 : -1), vb = (b >= 3 && b < 6) ? b - 3 : (b >= 6 ? b - 3 : -1);
+            double g = 0.0;
+            if (ua >= 0 && ub >= 0) g += Gs[ua * 16 + ub];
+            if (va >= 0 && vb >= 0) g += Gs[(8 + va) * 16 + 8 + vb];
+            A[tri(a, b)] = g;
+        }
         trace += A[tri(a, a)];
     }
     __syncthreads();
@@ -272,14 +304,22 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *tile, d
 #pragma unroll
     for (int a = 0; a < 9; a++) hv[a] = 1.0 / 3.0;
     for (int it = 0; it < 12; it++) {
+        double prev[9];
+#pragma unroll
+        for (int a = 0; a < 9; a++) prev[a] = hv[a];
         fwd_subst<9>(A, ipa, hv);
         bwd_subst<9>(A, ipa, hv);
         double nrm = 0.0;
 #pragma unroll
         for (int a = 0; a < 9; a++) nrm += hv[a] * hv[a];
-        nrm = 1.0 / sqrt(nrm);
+        nrm = rsqrt_pos(nrm);
+        double change = 0.0;
 #pragma unroll
-        for (int a = 0; a < 9; a++) hv[a] *= nrm;
+        for (int a = 0; a < 9; a++) {
+            hv[a] *= nrm;
+            change = fmax(change, fabs(hv[a] - prev[a]));
+        }
+        if (change < 1.0e-15) break;          // converged to rounding (typically 3-4 iterations)
     }
     // H = invHnorm * H0 * Hnorm2, scaled so that H[8] = 1
     const double i0 = 1.0 / sm0, i1 = 1.0 / sm1;
@@ -441,8 +481,8 @@ __device__ __forceinline__ void rodrigues_inv(const double R[9], double r[3]) {
 // residual-only / residual+Jacobian pass of the per-view LM
 __device__ double view_error(const float *obj, const float2 *img, int P, int lane, const double rt[6],
                              const double in[NINTR]) {
-    double R[9];
-    rodrigues_R(rt, R);
+    double R[9], K[9];
+    rodrigues_RK(rt, R, K);
     double s = 0.0;
     for (int c0 = 0; c0 < P; c0 += 64) {
         const int p = c0 + lane;
@@ -457,10 +497,11 @@ __device__ double view_error(const float *obj, const float2 *img, int P, int lan
     return wave_sum(s);
 }
 
+// JtJ (6x6 packed), Jt e and ||e||^2 of one view through the packed 8-column MFMA Gram
 __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int lane, const double rt[6],
                                  const double in[NINTR], double *tile, double *Gs, double JtJ[21], double JtErr[6]) {
-    double R[9], dR[27];
-    rodrigues(rt, R, dR);
+    double R[9], K[9];
+    rodrigues_RK(rt, R, K);
     d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     for (int c0 = 0; c0 < P; c0 += 64) {
         const int p = c0 + lane;
@@ -469,10 +510,12 @@ __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int
         const double M[3] = {(double)obj[3 * pc], (double)obj[3 * pc + 1], (double)obj[3 * pc + 2]};
         const float2 uv = img[pc];
         double mu[NCOL], mv[NCOL];
-        point_rows(M, (double)uv.x, (double)uv.y, R, dR, rt + 3, in, 0.0, mu, mv);
-        tile_store_rows(tile, lane, mu, mv, valid);
+        point_rows_K(M, (double)uv.x, (double)uv.y, R, K, rt + 3, in, 0.0, mu, mv);
+        const double ru[8] = {mu[0], mu[1], mu[2], mu[3], mu[4], mu[5], mu[COL_E], 0.0};
+        const double rv[8] = {mv[0], mv[1], mv[2], mv[3], mv[4], mv[5], mv[COL_E], 0.0};
+        tile8_store_rows(tile, lane, ru, rv, valid);
         __syncthreads();
-        tile_gram(tile, lane, min(64, P - c0), acc0, acc1);
+        tile8_gram(tile, lane, min(64, P - c0), acc0, acc1);
         __syncthreads();
     }
     gram_to_lds(Gs, lane, acc0, acc1);
@@ -480,10 +523,10 @@ __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int
 #pragma unroll
     for (int a = 0; a < 6; a++) {
 #pragma unroll
-        for (int b = 0; b <= a; b++) JtJ[tri(a, b)] = Gs[a * 16 + b];
-        JtErr[a] = Gs[a * 16 + COL_E];
+        for (int b = 0; b <= a; b++) JtJ[tri(a, b)] = Gs[a * 16 + b] + Gs[(8 + a) * 16 + 8 + b];
+        JtErr[a] = Gs[a * 16 + 6] + Gs[(8 + a) * 16 + 14];
     }
-    const double e2 = Gs[COL_E * 16 + COL_E];
+    const double e2 = Gs[6 * 16 + 6] + Gs[14 * 16 + 14];
     __syncthreads();
     return e2;
 }
@@ -516,7 +559,9 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
     pts.cMy = wave_sum(c1s) / P;
 
     double H[9], rt[6];
+    ISTAMP(0);
     const bool ok = wave_homography(pts, P, lane, s_tile, s_G, H);
+    ISTAMP(1);
     if (ok) {
         double h1[3] = {H[0], H[3], H[6]}, h2[3] = {H[1], H[4], H[7]}, h3[3] = {H[2], H[5], H[8]};
         const double n1 = sqrt(h1[0] * h1[0] + h1[1] * h1[1] + h1[2] * h1[2]);
@@ -551,7 +596,10 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
     for (int k = 0; k < 6; k++) { prev[k] = rt[k]; JtErr[k] = 0.0; }
 #pragma unroll
     for (int k = 0; k < 21; k++) JtJ[k] = 0.0;
+    ISTAMP(2);
     int lambdaLg10 = -3, iters = 0, state = 1;   // 1 STARTED, 2 CALC_J, 3 CHECK_ERR
+    int n_j = 0, n_e = 0;
+    (void)n_j; (void)n_e;
     double errNorm = 0.0, prevErrNorm = 0.0;
     const double *in = pts.in;
     for (int guard = 0; ok && guard < 20 * 24; guard++) {
@@ -592,9 +640,11 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
 #pragma unroll
             for (int k = 0; k < 6; k++) rt[k] = prev[k] - (pd ? d[k] : 0.0);
         }
-        if (state == 2) errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, in, s_tile, s_G, JtJ, JtErr));
-        else errNorm = sqrt(view_error(obj, img_i, P, lane, rt, in));
+        if (state == 2) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, in, s_tile, s_G, JtJ, JtErr)); n_j++; }
+        else { errNorm = sqrt(view_error(obj, img_i, P, lane, rt, in)); n_e++; }
     }
+    ISTAMP(3);
+    ICOUNT(4, n_j); ICOUNT(5, n_e); ICOUNT(6, iters);
     bool finite = true;
 #pragma unroll
     for (int k = 0; k < 6; k++) finite = finite && (fabs(rt[k]) < 1.0e300);

@@ -18,10 +18,41 @@ constexpr int TILE_LD = 34;           // doubles per corner: 2 rows x 16 columns
                                       // 16-B aligned b128 stores, 8 consecutive lanes hit 32 distinct banks)
 constexpr int TILE_D = 64 * TILE_LD;  // doubles per wave tile (17408 B)
 
+// DPP move of a double (two 32-bit halves); CTRL is a v_mov_b32_dpp control word
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false));
+}
+
+// Sum over the 64 lanes, same value (bits) in every lane.  Four DPP steps inside each row of 16
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: register-to-register, no LDS crossbar), then
+// the four row sums are read with v_readlane and added in row order.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);    // row_half_mirror
+    v += dpp_mov<0x140>(v);    // row_mirror
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double t = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    t += __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    t += __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    t += __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return t;
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+    v = fmax(v, dpp_mov<0xB1>(v));
+    v = fmax(v, dpp_mov<0x4E>(v));
+    v = fmax(v, dpp_mov<0x141>(v));
+    v = fmax(v, dpp_mov<0x140>(v));
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double t = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    t = fmax(t, __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16)));
+    t = fmax(t, __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32)));
+    t = fmax(t, __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48)));
+    return t;
 }
 
 // One lane stores its corner's two 16-wide rows (zeros when !valid) into the wave's tile.
@@ -63,6 +94,32 @@ __device__ __forceinline__ void tile_gram(const double *tile, int lane, int npts
         acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, a2, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, a3, acc1, 0, 0, 0);
         a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+    }
+}
+
+// Packed variant for systems of at most 8 columns (the 6-parameter pose polish: J | e): one corner
+// becomes ONE 16-wide tile row, its u-row in columns 0-7 and its v-row in columns 8-15, so the
+// product is [[Gu, X], [X^T, Gv]] and the wanted Gram matrix is Gu + Gv: half the LDS traffic and
+// half the MFMA steps of the 16-column form.
+constexpr int TILE8_LD = 18;          // doubles per corner: 16 + 2 pad (144 B, 16-B aligned)
+
+__device__ __forceinline__ void tile8_store_rows(double *tile, int lane, const double mu[8], const double mv[8],
+                                                 bool valid) {
+    double2 *dst = reinterpret_cast<double2 *>(tile + lane * TILE8_LD);
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        dst[c] = valid ? make_double2(mu[2 * c], mu[2 * c + 1]) : make_double2(0.0, 0.0);
+        dst[4 + c] = valid ? make_double2(mv[2 * c], mv[2 * c + 1]) : make_double2(0.0, 0.0);
+    }
+}
+
+__device__ __forceinline__ void tile8_gram(const double *tile, int lane, int npts, d4 &acc0, d4 &acc1) {
+    const int rd_off = (lane >> 4) * TILE8_LD + (lane & 15);   // k-step s: corners 4s .. 4s+3
+    const int nsteps = (((npts + 3) >> 2) + 1) & ~1;            // rounded up to even (zero rows beyond npts)
+    for (int s = 0; s < nsteps; s += 2) {
+        const double a0 = tile[s * 4 * TILE8_LD + rd_off], a1 = tile[(s + 1) * 4 * TILE8_LD + rd_off];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
     }
 }
 

@@ -42,3 +42,10 @@ with Solver(0) as s:
         a = np.array(buf[16:20], dtype=np.int64)
         print("   advance: state machine", a[0] - t[12], "assemble S", a[1] - a[0], "chol9", a[2] - a[1], "solves", a[3] - a[2],
               "tail", t[1] - a[3])
+
+    ib = (C.c_ulonglong * 16)()
+    L.ccal_debug_init_stamps.restype = C.c_int
+    L.ccal_debug_init_stamps(ib)
+    v = [int(x) for x in ib]
+    print("k_init_extrinsics (block 7): homography", v[1] - v[0], "cycles; decomposition", v[2] - v[1], "; pose LM", v[3] - v[2],
+          "cycles with", v[4], "Jacobian passes,", v[5], "error passes,", v[6], "iterations; homography polish iterations", v[7])
