@@ -74,15 +74,18 @@ def main():
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--images", type=int, default=None, help="override images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--allreduce", default=os.environ.get("CCAL_ALLREDUCE", "rccl"), choices=["rccl", "torch"],
-                    help="N > 1: 'rccl' = ncclAllReduce called by the library itself, 'torch' = torch.distributed hook")
+    ap.add_argument("--allreduce", default=os.environ.get("CCAL_ALLREDUCE", "p2p"), choices=["p2p", "rccl", "torch"],
+                    help="N > 1: 'p2p' = direct xGMI row exchange kernels (self-tested at start-up, else falls back), "
+                         "'rccl' = ncclAllReduce called by the library itself, 'torch' = torch.distributed hook")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: all ranks use cuda:0 and rendezvous over gloo (not a measurement)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
     from cameracalibrations_amd import synthetic as syn
-    from cameracalibrations_amd.distributed import TorchAllReduce, broadcast_id_via_torch
+    from cameracalibrations_amd.distributed import TorchAllReduce, allgather_bytes_via_torch, broadcast_id_via_torch
     from cameracalibrations_amd.solver import CRITERIA, Solver
 
     world = args.gpus
@@ -91,11 +94,17 @@ def main():
     if world > 1:
         assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run --nproc-per-node N"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.share_gpu:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
+    cdev = "cpu" if (world > 1 and args.share_gpu) else dev          # where torch.distributed tensors live
 
     # per-rank shard of the joint problem (different images on every rank, same camera)
     wl = syn.named_workload(args.workload, n_images=args.images, seed_offset=1000 * rank)
@@ -111,7 +120,29 @@ def main():
     def attach_comm(sol):
         if world == 1:
             return "none"
-        if args.allreduce == "rccl":
+
+        def all_agree(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+
+        if args.allreduce == "p2p":
+            why = ""
+            try:
+                sol.init_p2p(world, rank, N * world, allgather_bytes_via_torch())
+                ok = True
+            except Exception as exc:      # noqa: BLE001
+                ok, why = False, str(exc)
+            if all_agree(ok):
+                dist.barrier()            # every inbox is mapped before the first row is sent
+                try:
+                    sol.p2p_selftest(16)
+                except Exception as exc:  # noqa: BLE001
+                    ok, why = False, str(exc)
+                if all_agree(ok):
+                    return "p2p (direct xGMI row exchange kernels, self-tested)"
+            print(f"[bench] rank {rank}: direct exchange unavailable ({why or 'a peer failed'}); using RCCL", file=sys.stderr)
+        if args.allreduce in ("p2p", "rccl"):
             try:
                 sol.init_rccl(world, rank, N * world, broadcast_id_via_torch())
                 return "rccl (ncclAllReduce inside the library)"
@@ -141,7 +172,7 @@ def main():
     r = s.result()
     sweeps = (r["sweeps"] + r["reschur"]) * args.steps   # deterministic: every step repeats the same solve
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -198,7 +229,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not args.share_gpu else "synthetic (REHEARSAL: all ranks share one GPU, not a measurement)",
             "config": {"workload": f"{wl.name}: synthetic pinhole + k1,k2,p1,p2, {N} images x "
                                    f"{wl.n_corners[0]}x{wl.n_corners[1]} corners per GPU (BASELINE.json configs[2]), "
                                    f"one joint fit over {world} GPU(s)",

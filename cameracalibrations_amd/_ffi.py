@@ -67,6 +67,9 @@ SIGNATURES = {
     "ccal_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int32, C.c_int32, C.c_int64]),
     "ccal_comm_unique_id": (C.c_int, [C.c_char_p]),
     "ccal_comm_init_rank": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_int64]),
+    "ccal_p2p_export": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),
+    "ccal_p2p_connect": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "ccal_p2p_selftest": (C.c_int, [C.c_void_p, C.c_int32]),
     "ccal_set_problem": (C.c_int, [C.c_void_p, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double,
                                    C.c_uint32, C.c_int32, C.c_double]),
     "ccal_set_image_points": (C.c_int, [C.c_void_p, _fp]),

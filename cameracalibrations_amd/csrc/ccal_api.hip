@@ -24,7 +24,7 @@
 using namespace ccal;
 
 #ifdef CCAL_STAMPS
-namespace ccal { hipError_t debug_read_stamps(unsigned long long *out); hipError_t debug_read_init_stamps(unsigned long long *out); }
+namespace ccal { hipError_t debug_read_stamps(unsigned long long *out); hipError_t debug_read_init_stamps(unsigned long long *out); hipError_t debug_read_init_blocks(unsigned int *out); }
 #endif
 
 // prologue reduction: every workgroup sums the previous partials itself while they are few; beyond
@@ -83,6 +83,7 @@ struct ccal_ctx {
     void *ar_user = nullptr;
     int world = 1, rank = 0;
     Comm *comm = nullptr;              // native RCCL communicator (ccal_comm_init_rank)
+    P2P *p2p = nullptr;                // direct xGMI row exchange (ccal_p2p_export / ccal_p2p_connect)
     Detector *detector = nullptr;      // corner detector buffers (ccal_detect_corners)
     int64_t n_global = 0;
     int lm_batch = 8;
@@ -175,6 +176,7 @@ void ccal_destroy(ccal_ctx *c) {
     (void)hipHostFree(c->h_st); (void)hipHostFree(c->h_flags);
     for (auto &e : c->ev) (void)hipEventDestroy(e);
     delete c->comm;
+    delete c->p2p;
     delete c->detector;
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -195,6 +197,8 @@ int ccal_set_allreduce(ccal_ctx *c, ccal_allreduce_fn fn, void *user, int32_t wo
     c->graph_dirty = true;
     delete c->comm;
     c->comm = nullptr;
+    delete c->p2p;
+    c->p2p = nullptr;
     c->ar_fn = fn;                      // a hook with world_size == 1 is honoured (used by tests)
     c->ar_user = user;
     c->world = world_size;
@@ -224,9 +228,81 @@ int ccal_comm_init_rank(ccal_ctx *c, int32_t world_size, int32_t rank, const cha
     }
     c->graph_dirty = true;
     c->ar_fn = nullptr;
+    delete c->p2p;
+    c->p2p = nullptr;
     c->world = world_size;
     c->rank = rank;
     c->n_global = n_images_global;
+    return CCAL_OK;
+}
+
+static bool via_p2p_ready(const ccal_ctx *c) { return c->p2p && c->p2p->ready(); }
+
+int ccal_p2p_export(ccal_ctx *c, int32_t world_size, int32_t rank, char handle_out[64]) {
+    if (!c || !handle_out) return fail(CCAL_E_ARG, "ccal_p2p_export: NULL argument");
+    if (world_size < 1 || world_size > P2P_MAX_RANKS || rank < 0 || rank >= world_size)
+        return fail(CCAL_E_ARG, "ccal_p2p_export: bad rank/world (1..16 ranks of one node)");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    delete c->p2p;
+    c->p2p = new P2P();
+    std::string err;
+    if (c->p2p->create(world_size, rank, handle_out, err) != 0) {
+        delete c->p2p;
+        c->p2p = nullptr;
+        return fail(CCAL_E_COMM, err);
+    }
+    return CCAL_OK;
+}
+
+int ccal_p2p_connect(ccal_ctx *c, const char *handles, int64_t n_images_global) {
+    if (!c || !handles) return fail(CCAL_E_ARG, "ccal_p2p_connect: NULL argument");
+    if (!c->p2p) return fail(CCAL_E_STATE, "ccal_p2p_connect: ccal_p2p_export has not been called");
+    if (n_images_global < 1) return fail(CCAL_E_ARG, "ccal_p2p_connect: bad image count");
+    HIPCHK(hipSetDevice(c->device));
+    std::string err;
+    if (c->p2p->connect(handles, err) != 0) {
+        delete c->p2p;
+        c->p2p = nullptr;
+        return fail(CCAL_E_COMM, err);
+    }
+    c->graph_dirty = true;
+    c->ar_fn = nullptr;
+    delete c->comm;
+    c->comm = nullptr;
+    c->world = c->p2p->world();
+    c->rank = c->p2p->rank();
+    c->n_global = n_images_global;
+    return CCAL_OK;
+}
+
+int ccal_p2p_selftest(ccal_ctx *c, int32_t rounds) {
+    if (!c || rounds < 1) return fail(CCAL_E_ARG, "ccal_p2p_selftest: bad argument");
+    if (!via_p2p_ready(c)) return fail(CCAL_E_STATE, "ccal_p2p_selftest: ccal_p2p_connect has not been called");
+    HIPCHK(hipSetDevice(c->device));
+    const int W = c->p2p->world(), R = c->p2p->rank();
+    double *d = nullptr, h[P2P_MAX_DOUBLES];
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&d), sizeof h));
+    int bad = 0;
+    for (int t = 0; t < rounds && !bad; t++) {
+        // every rank contributes (rank + 1)(j + 1) + t / 7: the sum is exact in binary64 only if the
+        // ranks' rows are added in rank order on every rank, which is also what is checked
+        for (int j = 0; j < P2P_MAX_DOUBLES; j++) h[j] = (double)(R + 1) * (double)(j + 1) + (double)t / 7.0;
+        hipError_t e = hipMemcpyAsync(d, h, sizeof h, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = launch_p2p_allreduce(c->stream, c->p2p->dev(), d, P2P_MAX_DOUBLES);
+        if (e == hipSuccess) e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { (void)hipFree(d); HIPCHK(e); }
+        for (int j = 0; j < P2P_MAX_DOUBLES; j++) {
+            double want = 0.0;
+            for (int r = 0; r < W; r++) want += (double)(r + 1) * (double)(j + 1) + (double)t / 7.0;
+            if (h[j] != want) bad++;
+        }
+    }
+    (void)hipFree(d);
+    std::string err;
+    if (c->p2p->check_and_clear(err)) return fail(CCAL_E_COMM, "ccal_p2p_selftest: " + err);
+    if (bad) return fail(CCAL_E_COMM, "ccal_p2p_selftest: exchanged sums differ from the expected values");
     return CCAL_OK;
 }
 
@@ -337,9 +413,14 @@ int ccal_set_extrinsics(ccal_ctx *c, const double *rt_host) {
 }
 
 // ---- A4 / A5: closed-form initialisation on the device ---------------------------------
-static bool sharded(const ccal_ctx *c) { return c->ar_fn != nullptr || (c->comm && c->comm->ready()); }
+static bool via_p2p(const ccal_ctx *c) { return c->p2p && c->p2p->ready(); }
+static bool sharded(const ccal_ctx *c) { return c->ar_fn != nullptr || (c->comm && c->comm->ready()) || via_p2p(c); }
 
 static int run_allreduce(ccal_ctx *c, double *buf, int n) {
+    if (via_p2p(c)) {
+        HIPCHK(launch_p2p_allreduce(c->stream, c->p2p->dev(), buf, n));
+        return CCAL_OK;
+    }
     if (c->comm && c->comm->ready()) {
         std::string err;
         if (c->comm->all_reduce_sum(buf, n, c->stream, err) != 0) return fail(CCAL_E_COMM, err);
@@ -478,9 +559,22 @@ static int enqueue_trial(ccal_ctx *c, hipStream_t stream, int k, bool final_only
     t.first = k == 0;
     t.final_only = final_only ? 1 : 0;
     const int nb = lm_sweep_blocks(c->N);
+    if (via_p2p(c)) t.p2p = &c->p2p->dev();
     if (k > 0) {
         const double *prev = c->d_partials + (size_t)((k - 1) & 1) * nb * NRED;
-        if (sharded(c)) {
+        if (via_p2p(c)) {
+            if (nb > DIRECT_MAX_BLOCKS) {
+                // one launch: condense the partials, exchange the row with the peers over xGMI, sum in rank order
+                HIPCHK(launch_lm_exchange(stream, prev, nb, c->d_red, c->p2p->dev(), k));
+                t.rows_in = c->d_red;
+                t.n_in = 1;
+            } else {
+                // the prologue of the trial sums the local rows and exchanges the result itself
+                t.rows_in = prev;
+                t.n_in = nb;
+                t.xchg_fused = 1;
+            }
+        } else if (sharded(c)) {
             // 16 workgroups condense the partials (one would be bound by a single CU's ~64 GB/s); the
             // 16 rows (8.7 KB, still latency-bound) are summed across GPUs and added up in the prologue
             // (always 16: the message size must not depend on the local shard size; surplus rows are zero)
@@ -533,12 +627,13 @@ int ccal_lm_run(ccal_ctx *c) {
     const double t0 = now_s();
     // upper bound on trials: every accepted iteration may be preceded by lambda climbing
     // from -16 to 16 (rejections + re-damping sweeps)
-    const long max_trials = 8L + (long)c->max_iter * 70L;
+    long max_trials = 8L + (long)c->max_iter * 70L;
+    if (via_p2p(c) && max_trials > 65000L) max_trials = 65000L;   // the exchange tag carries the trial index in 16 bits
     long trials = 0;
     c->ev_used = 0;
     c->h_st->done = 0;
     *progress_word(c) = 0ull;
-    const bool graphed = c->use_graph && !c->time_sweeps && !sharded(c);
+    const bool graphed = c->use_graph && !c->time_sweeps && (!sharded(c) || via_p2p(c));
     if (graphed) {
         ccal_ctx::GraphKey key;
         memset(&key, 0, sizeof key);
@@ -576,6 +671,10 @@ int ccal_lm_run(ccal_ctx *c) {
         trials += more;
         if ((rc = enqueue_trial(c, c->stream, (int)trials, true)) != CCAL_OK) return rc;
         if ((rc = wait_progress(c, trials)) != CCAL_OK) return rc;
+    }
+    if (via_p2p(c)) {
+        std::string err;
+        if (c->p2p->check_and_clear(err)) return fail(CCAL_E_COMM, "ccal_lm_run: " + err);
     }
     const LmState &r = *c->h_st;
     c->stats.t_lm_s = now_s() - t0;
@@ -921,6 +1020,11 @@ int ccal_time_sweep(ccal_ctx *c, int32_t reps, double *avg_us) {
 int ccal_debug_init_stamps(unsigned long long *out) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(ccal::debug_read_init_stamps(out));
+    return CCAL_OK;
+}
+int ccal_debug_init_blocks(unsigned int *out) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(ccal::debug_read_init_blocks(out));
     return CCAL_OK;
 }
 int ccal_debug_stamps(unsigned long long *out) {

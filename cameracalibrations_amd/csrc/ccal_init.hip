@@ -22,6 +22,13 @@ namespace ccal {
 
 #ifdef CCAL_STAMPS
 __device__ unsigned long long g_init_stamps[16];
+__device__ unsigned int g_init_blk[4096 * 4];   // per block: total cycles, homography polish iters, pose LM iters, Jacobian passes
+#define IBLK(j, v) do { if (blockIdx.x < 4096 && threadIdx.x == 0) g_init_blk[blockIdx.x * 4 + (j)] = (unsigned int)(v); } while (0)
+static __device__ __forceinline__ unsigned long long memtime_now() {
+    unsigned long long t_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+    return t_;
+}
 #define ISTAMP(i)                                                                             \
     do {                                                                                      \
         if (blockIdx.x == 7 && threadIdx.x == 0) {                                            \
@@ -34,7 +41,11 @@ __device__ unsigned long long g_init_stamps[16];
 hipError_t debug_read_init_stamps(unsigned long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_init_stamps), sizeof(unsigned long long) * 16);
 }
+hipError_t debug_read_init_blocks(unsigned int *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_init_blk), sizeof(unsigned int) * 4096 * 4);
+}
 #else
+#define IBLK(j, v) do { } while (0)
 #define ISTAMP(i) do { } while (0)
 #define ICOUNT(i, v) do { } while (0)
 #endif
@@ -228,7 +239,7 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *tile, doub
             rmax = rdmax;
         }
         iter++;
-        if (!(iter < 10 && dmax >= FLT_EPS && rmax >= FLT_EPS)) { ICOUNT(7, iter); break; }
+        if (!(iter < 10 && dmax >= FLT_EPS && rmax >= FLT_EPS)) { ICOUNT(7, iter); IBLK(1, iter); break; }
     }
 }
 
@@ -559,6 +570,9 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
     pts.cMy = wave_sum(c1s) / P;
 
     double H[9], rt[6];
+#ifdef CCAL_STAMPS
+    const unsigned long long t_begin = memtime_now();
+#endif
     ISTAMP(0);
     const bool ok = wave_homography(pts, P, lane, s_tile, s_G, H);
     ISTAMP(1);
@@ -645,6 +659,9 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
     }
     ISTAMP(3);
     ICOUNT(4, n_j); ICOUNT(5, n_e); ICOUNT(6, iters);
+#ifdef CCAL_STAMPS
+    IBLK(0, memtime_now() - t_begin); IBLK(2, iters); IBLK(3, n_j);
+#endif
     bool finite = true;
 #pragma unroll
     for (int k = 0; k < 6; k++) finite = finite && (fabs(rt[k]) < 1.0e300);

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "ccal_p2p.hpp"
 #include "ccal_state.hpp"
 
 namespace ccal {
@@ -25,9 +26,14 @@ struct TrialLaunch {              // one launch of k_lm_trial (see ccal_lm.hip)
     double *gram_out = nullptr;
     int N = 0, P = 0, k = 0, first = 0, final_only = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // optional: timestamps of this dispatch
+    const P2PDev *p2p = nullptr;  // image-sharded fit: launch the exchanging instantiation
+    int xchg_fused = 0;           // ... whose prologue runs the row exchange itself
 };
 hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t);
 hipError_t launch_lm_reduce(hipStream_t stream, const double *rows, int n_rows, double *out, int G);
+// multi-GPU, many partial rows: partial rows -> one row -> sum over the node's ranks by direct xGMI
+// exchange -> out[0..68), as exchange k of the current solve (few rows: fused into k_lm_trial)
+hipError_t launch_lm_exchange(hipStream_t stream, const double *rows, int n_rows, double *out, const P2PDev &p, int k);
 
 // ccal_init.hip -- closed-form initialisation
 constexpr int NFOC = 8;   // doubles all-reduced for the focal least squares: AtA(3) Atb(2) fail(1) pad(2)

@@ -29,12 +29,17 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <cstring>
+
 #include "ccal_kernels.hpp"
 #include "ccal_math.hpp"
+#include "ccal_p2p_dev.hpp"
 #include "ccal_state.hpp"
 #include "ccal_wave.hpp"
 
 namespace ccal {
+
+static_assert(P2P_MAX_DOUBLES == NRED, "the exchanged row is one reduced system");
 
 constexpr int WAVES = 4;             // images per workgroup
 
@@ -279,6 +284,8 @@ struct TrialArgs {
     int N, P, k;
     int first;                    // k == 0: build S_0 instead of advancing
     int final_only;               // prologue only (detect termination, report to the host)
+    int xchg_fused;               // image-sharded fit: the prologue exchanges the local row with the peer GPUs
+    P2PDev p2p;                   // used by the XCHG instantiation only
 };
 
 // S_0: the state OpenCV's loop starts from
@@ -314,11 +321,17 @@ __device__ void lm_boot(LmState *ls, const LmInit &init, const double *intr0, in
 // ---------------------------------------------------------------------------------------
 // one LM trial
 // ---------------------------------------------------------------------------------------
+// XCHG = image-sharded fit over the GPUs of one node (ccal_p2p.hpp): between the local row sum and
+// the LM advance the prologue stores the row into the peers' inboxes (workgroup 0) and adds the
+// peers' rows from the local inbox in rank order (every workgroup) -- the whole all-reduce, with
+// no launch of its own.  The first launch of a solve takes the next sequence number.
+template <bool XCHG>
 __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
     __shared__ __attribute__((aligned(16))) double s_wave[WAVES * TILE_D];
     __shared__ __attribute__((aligned(16))) double s_red[WAVES * NRED];
     __shared__ __attribute__((aligned(16))) double s_part[RED_SLICES * NRED];
     __shared__ __attribute__((aligned(16))) double s_rs[NRED];
+    __shared__ double s_all[XCHG ? P2P_MAX_RANKS * NRED : 1];
     __shared__ LmState ls;
 
     const int tid = threadIdx.x;
@@ -352,8 +365,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
     tri_decode(lane < 45 ? lane : 0, oa, ob);
 
     // ---- 1. the state of this trial, S_k, in LDS (every workgroup computes the same bits) ----
+    unsigned int seq = 0;
+    if constexpr (XCHG) seq = __hip_atomic_load(A.p2p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (A.first) {
         lm_boot(&ls, A.init, A.intr0, tid);
+        // no other workgroup of this launch reads the sequence number; the launches after it see seq + 1
+        if constexpr (XCHG)
+            if (blockIdx.x == 0 && tid == 0)
+                __hip_atomic_store(A.p2p.epoch, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         const LmState *prev = A.st + ((A.k - 1) & 1);
         RedRegs q;
@@ -362,8 +381,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
             reinterpret_cast<double *>(&ls)[i] = reinterpret_cast<const double *>(prev)[i];
         __syncthreads();
         STAMP(11);
-        if (ls.done) return;                    // solve already terminated: surplus launch
+        if (ls.done) {
+            // solve already terminated: surplus launch.  The terminal state is carried along, so every
+            // later launch of the batch sees it too (none of them sweeps or exchanges again).
+            if (blockIdx.x == 0) {
+                LmState *cur = A.st + (A.k & 1);
+                for (int i = tid; i < STATE_WORDS; i += WAVES * 64)
+                    reinterpret_cast<double *>(cur)[i] = reinterpret_cast<const double *>(&ls)[i];
+            }
+            return;
+        }
         reduce_finish(A.rows_in, A.n_in, s_part, s_rs, tid, q);
+        if constexpr (XCHG)
+            if (A.xchg_fused)
+                p2p_exchange_rows(A.p2p, p2p_tag(seq, (unsigned)A.k), p2p_slot(seq, (unsigned)A.k), s_rs, s_all, NRED, tid,
+                                  blockIdx.x == 0);
         STAMP(12);
         if (tid == 0) {
             if (blockIdx.x == 0) lm_advance<true>(&ls, s_rs, A.trace);
@@ -598,6 +630,54 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_reduce(const double *__restri
 }
 
 // ---------------------------------------------------------------------------------------
+// multi-GPU: partial rows -> one row -> sum over the ranks of the node (xGMI exchange,
+// ccal_p2p.hpp) -> out[0..68).  ONE workgroup of 1024 threads: 30 slices x 34 column pairs pull
+// the local rows with every load in flight at once (a hand-off between workgroups -- release
+// fence + counter -- costs more than the 136 KB a single CU has to read), combine in fixed
+// order and run the exchange.  Used only when there are too many partial rows for every
+// workgroup of k_lm_trial to sum them (then the exchange is fused into its prologue instead).
+// ---------------------------------------------------------------------------------------
+constexpr int XCH_THREADS = 1024;
+constexpr int XCH_SLICES = 30;      // 30 * RED_PAIRS = 1020 active threads
+constexpr int XCH_UNROLL = 9;       // 270 rows per pass
+
+__global__ __launch_bounds__(XCH_THREADS) void k_lm_exchange(const double *__restrict__ rows, int n_rows,
+                                                              double *__restrict__ out, P2PDev p, int k) {
+    __shared__ __attribute__((aligned(16))) double s_part[XCH_SLICES * NRED];
+    __shared__ double s_val[NRED];
+    __shared__ double s_all[P2P_MAX_RANKS * NRED];
+    const int tid = threadIdx.x;
+    const int j2 = tid % RED_PAIRS, c = tid / RED_PAIRS;
+    if (c < XCH_SLICES) {
+        double s0 = 0.0, s1 = 0.0;
+        const double2 *src = reinterpret_cast<const double2 *>(rows) + j2;
+        for (int r0 = c; r0 < n_rows; r0 += XCH_SLICES * XCH_UNROLL) {
+            double2 v[XCH_UNROLL];
+#pragma unroll
+            for (int k = 0; k < XCH_UNROLL; k++) {
+                const int r = r0 + k * XCH_SLICES;
+                v[k] = r < n_rows ? src[(size_t)r * RED_PAIRS] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int k = 0; k < XCH_UNROLL; k++) { s0 += v[k].x; s1 += v[k].y; }
+        }
+        s_part[c * NRED + 2 * j2] = s0;
+        s_part[c * NRED + 2 * j2 + 1] = s1;
+    }
+    __syncthreads();
+    if (tid < NRED) {
+        double t = s_part[tid];
+#pragma unroll
+        for (int k = 1; k < XCH_SLICES; k++) t += s_part[k * NRED + tid];
+        s_val[tid] = t;
+    }
+    __syncthreads();
+    const unsigned int seq = __hip_atomic_load(p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p2p_exchange_rows(p, p2p_tag(seq, (unsigned)k), p2p_slot(seq, (unsigned)k), s_val, s_all, NRED, tid, true);
+    if (tid < NRED) out[tid] = s_val[tid];
+}
+
+// ---------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------
 int lm_sweep_blocks(int N) { return (N + WAVES - 1) / WAVES; }
@@ -609,16 +689,32 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     a.host_progress = t.host_progress; a.intr0 = t.intr0; a.ext0 = t.ext0; a.ext0_stride = t.ext0_stride;
     a.init = t.init; a.gram_out = t.gram_out; a.N = t.N; a.P = t.P; a.k = t.k; a.first = t.first;
     a.final_only = t.final_only;
+    a.xchg_fused = 0;
+    memset(&a.p2p, 0, sizeof a.p2p);
     const int grid = t.final_only ? 1 : lm_sweep_blocks(t.N);
+    if (t.p2p != nullptr) {
+        a.p2p = *t.p2p;
+        a.xchg_fused = t.xchg_fused;
+        if (t.ev_start != nullptr && t.ev_stop != nullptr)
+            hipExtLaunchKernelGGL(k_lm_trial<true>, dim3(grid), dim3(WAVES * 64), 0, stream, t.ev_start, t.ev_stop, 0, a);
+        else
+            hipLaunchKernelGGL(k_lm_trial<true>, dim3(grid), dim3(WAVES * 64), 0, stream, a);
+        return hipGetLastError();
+    }
     if (t.ev_start != nullptr && t.ev_stop != nullptr)   // events bound to this dispatch: its own begin / end
-        hipExtLaunchKernelGGL(k_lm_trial, dim3(grid), dim3(WAVES * 64), 0, stream, t.ev_start, t.ev_stop, 0, a);
+        hipExtLaunchKernelGGL(k_lm_trial<false>, dim3(grid), dim3(WAVES * 64), 0, stream, t.ev_start, t.ev_stop, 0, a);
     else
-        hipLaunchKernelGGL(k_lm_trial, dim3(grid), dim3(WAVES * 64), 0, stream, a);
+        hipLaunchKernelGGL(k_lm_trial<false>, dim3(grid), dim3(WAVES * 64), 0, stream, a);
     return hipGetLastError();
 }
 
 hipError_t launch_lm_reduce(hipStream_t stream, const double *rows, int n_rows, double *out, int G) {
     hipLaunchKernelGGL(k_lm_reduce, dim3(G), dim3(WAVES * 64), 0, stream, rows, n_rows, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_lm_exchange(hipStream_t stream, const double *rows, int n_rows, double *out, const P2PDev &p, int k) {
+    hipLaunchKernelGGL(k_lm_exchange, dim3(1), dim3(XCH_THREADS), 0, stream, rows, n_rows, out, p, k);
     return hipGetLastError();
 }
 

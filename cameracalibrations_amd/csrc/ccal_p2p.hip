@@ -1,0 +1,103 @@
+// ccal_p2p.hip -- inbox allocation / IPC mapping and the generic small all-reduce kernel of the
+// xGMI row exchange (protocol: ccal_p2p.hpp, device side: ccal_p2p_dev.hpp).
+#include "ccal_p2p.hpp"
+
+#include <cstdlib>
+#include <cstring>
+
+#include "ccal_p2p_dev.hpp"
+
+namespace ccal {
+
+static_assert(sizeof(hipIpcMemHandle_t) == P2P_HANDLE_BYTES, "IPC handle size");
+
+#define P2PCHK(x)                                                                              \
+    do {                                                                                       \
+        const hipError_t e_ = (x);                                                             \
+        if (e_ != hipSuccess) {                                                                \
+            err = std::string(#x) + ": " + hipGetErrorString(e_);                              \
+            return -1;                                                                         \
+        }                                                                                      \
+    } while (0)
+
+P2P::~P2P() {
+    if (!created_) return;
+    (void)hipSetDevice(device_);
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < dev_.world; r++)
+        if (connected_ && r != dev_.rank && dev_.peer[r]) (void)hipIpcCloseMemHandle(dev_.peer[r]);
+    (void)hipFree(dev_.inbox);
+    (void)hipFree(dev_.epoch);
+    (void)hipHostFree(dev_.err);
+}
+
+int P2P::create(int world, int rank, char handle_out[P2P_HANDLE_BYTES], std::string &err) {
+    if (created_) { err = "P2P::create called twice"; return -1; }
+    if (world < 1 || world > P2P_MAX_RANKS || rank < 0 || rank >= world) { err = "P2P: bad world/rank (at most 16 ranks)"; return -1; }
+    P2PCHK(hipGetDevice(&device_));
+    memset(&dev_, 0, sizeof dev_);
+    dev_.world = world;
+    dev_.rank = rank;
+    // fine-grained: remote stores land coherently and local polls are not served from a stale L2 line
+    P2PCHK(hipExtMallocWithFlags(reinterpret_cast<void **>(&dev_.inbox), P2P_INBOX_WORDS * 8, hipDeviceMallocFinegrained));
+    P2PCHK(hipMemset(dev_.inbox, 0, P2P_INBOX_WORDS * 8));
+    unsigned int *words = nullptr;
+    P2PCHK(hipMalloc(reinterpret_cast<void **>(&words), 64));
+    P2PCHK(hipMemset(words, 0, 64));
+    dev_.epoch = words;
+    // the time-out flag lives in pinned host memory: the host reads it without a copy
+    P2PCHK(hipHostMalloc(reinterpret_cast<void **>(&dev_.err), 64, hipHostMallocMapped));
+    *dev_.err = 0;
+    P2PCHK(hipDeviceSynchronize());
+    double ms = 5000.0;
+    if (const char *s = getenv("CCAL_P2P_TIMEOUT_MS")) { const double v = atof(s); if (v > 0) ms = v; }
+    dev_.budget = (long long)(ms * 1.0e5);   // wall_clock64 counts at 100 MHz
+    hipIpcMemHandle_t h;
+    P2PCHK(hipIpcGetMemHandle(&h, dev_.inbox));
+    memcpy(handle_out, &h, P2P_HANDLE_BYTES);
+    dev_.peer[rank] = dev_.inbox;
+    created_ = true;
+    return 0;
+}
+
+int P2P::connect(const char *handles, std::string &err) {
+    if (!created_) { err = "P2P::connect before create"; return -1; }
+    if (connected_) { err = "P2P::connect called twice"; return -1; }
+    P2PCHK(hipSetDevice(device_));
+    for (int r = 0; r < dev_.world; r++) {
+        if (r == dev_.rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)r * P2P_HANDLE_BYTES, P2P_HANDLE_BYTES);
+        void *p = nullptr;
+        P2PCHK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        dev_.peer[r] = static_cast<unsigned long long *>(p);
+    }
+    connected_ = true;
+    return 0;
+}
+
+int P2P::check_and_clear(std::string &err) {
+    volatile int *flag = dev_.err;
+    if (*flag == 0) return 0;
+    *flag = 0;
+    err = "xGMI row exchange timed out waiting for a peer rank";
+    return 1;
+}
+
+__global__ __launch_bounds__(256) void k_p2p_allreduce(P2PDev p, double *buf, int n) {
+    __shared__ double s_val[P2P_MAX_DOUBLES];
+    __shared__ double s_all[P2P_MAX_RANKS * P2P_MAX_DOUBLES];
+    const int tid = threadIdx.x;
+    if (tid < n) s_val[tid] = buf[tid];
+    __syncthreads();
+    p2p_allreduce_wg(p, s_val, s_all, n, tid);
+    if (tid < n) buf[tid] = s_val[tid];
+}
+
+hipError_t launch_p2p_allreduce(hipStream_t stream, const P2PDev &p, double *buf, int n) {
+    if (n < 1 || n > P2P_MAX_DOUBLES) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(256), 0, stream, p, buf, n);
+    return hipGetLastError();
+}
+
+}  // namespace ccal

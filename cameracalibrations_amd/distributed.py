@@ -68,6 +68,20 @@ def broadcast_id_via_torch(group=None):
     return bcast
 
 
+def allgather_bytes_via_torch(group=None):
+    """-> allgather_bytes callable for Solver.init_p2p: every rank's inbox handle, in rank order."""
+    import torch
+    import torch.distributed as dist
+
+    def gather(b):
+        dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        out = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(out, t, group=group)
+        return [bytes(o.cpu().numpy().tobytes()) for o in out]
+    return gather
+
+
 def reduced_system_from_gram(G, lam, mask=None):
     """numpy mirror of one image's contribution to the 68-double reduced system of the device
     kernels: A, g, SC = B C_l^-1 B^T, sg = B C_l^-1 h, err.  Used by the CPU

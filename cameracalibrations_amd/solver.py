@@ -69,6 +69,23 @@ class Solver:
         assert len(ident) == 128
         F.check(F.lib().ccal_comm_init_rank(self._h, int(world_size), int(rank), ident, int(n_images_global)))
 
+    def init_p2p(self, world_size, rank, n_images_global, allgather_bytes):
+        """Direct xGMI row exchange between the GPUs of one node (no collective library).
+        `allgather_bytes(b: bytes) -> list[bytes]` returns every rank's 64-byte inbox handle in
+        rank order (e.g. through torch.distributed)."""
+        buf = C.create_string_buffer(64)
+        rc = F.lib().ccal_p2p_export(self._h, int(world_size), int(rank), buf)
+        handles = allgather_bytes(buf.raw if rc == 0 else bytes(64))   # the gather is collective: always join it
+        F.check(rc)
+        assert len(handles) == world_size and all(len(h) == 64 for h in handles)
+        if any(h == bytes(64) for h in handles):
+            raise RuntimeError("init_p2p: a peer rank could not export its inbox")
+        F.check(F.lib().ccal_p2p_connect(self._h, b"".join(handles), int(n_images_global)))
+
+    def p2p_selftest(self, rounds=8):
+        """Exchanges known rows `rounds` times and checks the sums (all ranks call it together)."""
+        F.check(F.lib().ccal_p2p_selftest(self._h, int(rounds)))
+
     def set_problem(self, obj, n_images, image_size, aspect=1.0, flags=0, max_iter=30, eps=1e-3):
         """obj (P,3); image_size = (width, height) as OpenCV sees it (src/detect_fit.jl:32)."""
         obj, op = F.f32(obj)

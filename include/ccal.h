@@ -117,6 +117,22 @@ int  ccal_comm_unique_id(char id_out[128]);
 int  ccal_comm_init_rank(ccal_ctx *ctx, int32_t world_size, int32_t rank, const char id[128],
                          int64_t n_images_global);
 
+/* Direct variant for the GPUs of ONE node (the default of bench.py): no collective library at
+ * all.  The per-trial message is one 544-byte row, so its cost is pure latency; each rank owns an
+ * inbox in fine-grained device memory, peers map it through HIP IPC and store their row straight
+ * into it over xGMI ({epoch | 32 payload bits} words), the receiver sums the rows in rank order
+ * (bit-identical on every rank).  The exchange is a kernel on the launch stream, so a sharded
+ * solve is one hipGraph like a single-GPU one.  Every rank calls ccal_p2p_export (64-byte
+ * handle out), the handles are all-gathered by any means (rank order, world x 64 bytes), then
+ * every rank calls ccal_p2p_connect.  At most 16 ranks.  A peer that does not show up within
+ * CCAL_P2P_TIMEOUT_MS (default 5000) makes the solve return CCAL_E_COMM instead of hanging.
+ * Replaces any hook / RCCL communicator set before. */
+int  ccal_p2p_export(ccal_ctx *ctx, int32_t world_size, int32_t rank, char handle_out[64]);
+int  ccal_p2p_connect(ccal_ctx *ctx, const char *handles, int64_t n_images_global);
+/* `rounds` exchanges of known rows, checked on the host (every rank must call it with the same
+ * count): CCAL_OK, or CCAL_E_COMM when a peer stayed silent or a sum came back wrong. */
+int  ccal_p2p_selftest(ccal_ctx *ctx, int32_t rounds);
+
 /* ---- problem ------------------------------------------------------------------------ */
 /* Replaces the marshalling of fit_model (src/detect_fit.jl:30-45): template, image size
  * (width, height) as OpenCV sees it == Julia size(img) (src/detect_fit.jl:32), aspect

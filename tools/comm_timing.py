@@ -1,5 +1,6 @@
 """Per-solve cost of the multi-GPU code path at world_size 1 (one GPU box): graph path vs
-reduce -> all-reduce -> solve with the torch hook vs the library's own RCCL communicator."""
+reduce -> all-reduce -> solve with the torch hook vs the library's own RCCL communicator vs the
+direct exchange kernels (one launch between trials, graph-captured)."""
 import os
 import sys
 import time
@@ -10,7 +11,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from cameracalibrations_amd import synthetic as syn  # noqa: E402
-from cameracalibrations_amd.distributed import TorchAllReduce, broadcast_id_via_torch  # noqa: E402
+from cameracalibrations_amd.distributed import TorchAllReduce, allgather_bytes_via_torch, broadcast_id_via_torch  # noqa: E402
 from cameracalibrations_amd.solver import Solver  # noqa: E402
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -27,6 +28,8 @@ def run(kind):
         s.set_image_points(img)
         if kind == "torch":
             s.set_allreduce(TorchAllReduce(), 1, 0, wl.n_images)
+        elif kind == "p2p":
+            s.init_p2p(1, 0, wl.n_images, allgather_bytes_via_torch())
         elif kind == "rccl":
             s.init_rccl(1, 0, wl.n_images, broadcast_id_via_torch())
         s.init_intrinsics()
@@ -43,6 +46,6 @@ def run(kind):
         print(f"{kind:6s}: {1e6 * dt:8.1f} us per solve ({r['sweeps']} sweeps, {1e6 * dt / r['sweeps']:.1f} us per trial)")
 
 
-for k in ("graph", "rccl", "torch"):
+for k in ("graph", "p2p", "rccl", "torch"):
     run(k)
 dist.destroy_process_group()

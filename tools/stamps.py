@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "cameracalibrations_amd", "csrc")
 OUT = "/tmp/libccal_hip_stamps.so"
-srcs = [os.path.join(CSRC, f) for f in ("ccal_lm.hip", "ccal_init.hip", "ccal_maps.hip", "ccal_comm.hip", "ccal_detect.hip", "ccal_api.hip")]
+srcs = [os.path.join(CSRC, f) for f in ("ccal_lm.hip", "ccal_init.hip", "ccal_maps.hip", "ccal_comm.hip", "ccal_p2p.hip", "ccal_detect.hip", "ccal_api.hip")]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                        "-DCCAL_STAMPS", "-o", OUT, *srcs, "-ldl"])
 from cameracalibrations_amd import _ffi as F  # noqa: E402
@@ -49,3 +49,11 @@ with Solver(0) as s:
     v = [int(x) for x in ib]
     print("k_init_extrinsics (block 7): homography", v[1] - v[0], "cycles; decomposition", v[2] - v[1], "; pose LM", v[3] - v[2],
           "cycles with", v[4], "Jacobian passes,", v[5], "error passes,", v[6], "iterations; homography polish iterations", v[7])
+
+    bb = (C.c_uint * (4096 * 4))()
+    L.ccal_debug_init_blocks.restype = C.c_int
+    L.ccal_debug_init_blocks(bb)
+    b = np.array(bb[:], dtype=np.int64).reshape(4096, 4)[:1000]
+    print("per-image k_init_extrinsics cycles: min %d median %d p90 %d max %d" % (b[:, 0].min(), np.median(b[:, 0]), np.percentile(b[:, 0], 90), b[:, 0].max()))
+    for j, n in ((1, "homography polish iters"), (2, "pose LM iters"), (3, "pose Jacobian passes")):
+        print("  ", n, np.bincount(b[:, j]).tolist())
