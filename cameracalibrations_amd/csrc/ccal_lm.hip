@@ -331,8 +331,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
     __shared__ __attribute__((aligned(16))) double s_red[WAVES * NRED];
     __shared__ __attribute__((aligned(16))) double s_part[RED_SLICES * NRED];
     __shared__ __attribute__((aligned(16))) double s_rs[NRED];
-    __shared__ double s_all[XCHG ? P2P_MAX_RANKS * NRED : 1];
     __shared__ LmState ls;
+    double *s_all = s_wave;       // XCHG: the peers' rows are staged in the (not yet used) tile space
+    static_assert(P2P_MAX_RANKS * NRED <= WAVES * TILE_D, "exchange staging exceeds the tile space");
 
     const int tid = threadIdx.x;
     STAMP(0);

@@ -4,6 +4,7 @@ import csv
 import glob
 import json
 import os
+import re
 import statistics
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +18,8 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             for row in csv.DictReader(open(f)):
                 if row.get("Counter_Name") != ctr:
                     continue
-                name = row["Kernel_Name"].split("(")[0]
+                # "void ccal::k_lm_trial<false>(ccal::TrialArgs)" -> "ccal::k_lm_trial" (single-GPU instantiation)
+                name = re.sub(r"<.*>", "", row["Kernel_Name"].split("(")[0]).replace("void ", "").strip()
                 if name == "ccal::k_lm_trial" and int(row["Grid_Size"]) <= 256:
                     name += "[prologue-only]"       # the terminating launch of a solve: one workgroup, no sweep
                 vals.setdefault(name, []).append(float(row["Counter_Value"]))

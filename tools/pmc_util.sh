@@ -18,7 +18,7 @@ root = os.environ.get("GRAFT_REPO_ROOT", ".")
 out = {}
 for f in glob.glob(os.path.join(root, "gpurun_out/pmc_util/*/**/*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        if not row["Kernel_Name"].startswith("ccal::k_lm_trial") or int(row["Grid_Size"]) <= 256:
+        if "ccal::k_lm_trial" not in row["Kernel_Name"] or int(row["Grid_Size"]) <= 256:
             continue
         out.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 summary = {k: {"launches": len(v), "mean": statistics.mean(v)} for k, v in sorted(out.items())}
