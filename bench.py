@@ -137,6 +137,11 @@ def main():
                 dist.barrier()            # every inbox is mapped before the first row is sent
                 try:
                     sol.p2p_selftest(16)
+                    # ... and the real thing: init (8-double exchange) + two sharded solves (fused exchange, graph replay)
+                    sol.init_intrinsics()
+                    sol.init_extrinsics()
+                    sol.lm_run()
+                    sol.lm_run()
                 except Exception as exc:  # noqa: BLE001
                     ok, why = False, str(exc)
                 if all_agree(ok):

@@ -100,41 +100,70 @@ __device__ __forceinline__ double pow10_lg(const LmState *st, int lg) { return s
 // BOOK = true (workgroup 0 only, whose copy is persisted) also keeps the books the host reads:
 // trace, per-trial kinds, counters, the reported relative step.
 template <bool BOOK>
-__device__ __forceinline__ void lm_advance(LmState *st, const double *rs, TraceRec *trace) {
+__device__ __forceinline__ void lm_advance(LmState *__restrict__ st, const double *__restrict__ rs, TraceRec *trace) {
+    // Everything the decision needs is pulled out of LDS in ONE burst of independent reads (the
+    // reduced row, the scalars of the state, both intrinsic vectors): one lane runs this, so every
+    // dependent LDS round trip in the middle of the logic would be paid in full.
+    double r[NRED];
+#pragma unroll
+    for (int o = 0; o < NRED; o++) r[o] = rs[o];
     const int mode = st->mode;
-    const double err = rs[RED_ERR];
-    if (BOOK) {
-        if (st->trials < MAX_KINDS) st->kinds[st->trials] = 1 + mode;
-        st->n_bad = (int)rs[RED_BAD];
+    const int lam_lg0 = st->lambda_lg10;
+    int lam_lg = lam_lg0;
+    const int lg_part = st->lg_partials, iters0 = st->iters, max_iter = st->max_iter, trials0 = st->trials;
+    const double prev_err = st->prev_err, eps = st->eps, aspect = st->aspect;
+    double ip[9], ic[9];
+    bool freep[9];
+#pragma unroll
+    for (int a = 0; a < 9; a++) {
+        ip[a] = st->intr_prev[a];
+        ic[a] = st->intr_cand[a];
+        freep[a] = st->mask[a] != 0 && r[RED_DA + a] > 0.0;   // fixed / unobservable: delta = 0
     }
-    st->trials++;
+    // the three lambdas a decision can ask for (dynamic table reads issued with the burst)
+    const double lam_up = pow10_lg(st, min(lam_lg0 + 1, 16)), lam_dn = pow10_lg(st, max(lam_lg0 - 1, -16)),
+                 lam_dn2 = pow10_lg(st, max(lam_lg0 - 2, -16)), lam_same = pow10_lg(st, lam_lg0);
+    auto pow10_sel = [&](int lg) -> double {       // 10^lg from the pre-read values when it is one of them
+        return lg == lam_lg0 ? lam_same : (lg == lam_lg0 - 1 ? lam_dn : (lg == lam_lg0 - 2 ? lam_dn2 : (lg == lam_lg0 + 1 ? lam_up : pow10_lg(st, lg))));
+    };
+    const double err = r[RED_ERR];
+    if (BOOK) {
+        if (trials0 < MAX_KINDS) st->kinds[trials0] = 1 + mode;
+        st->n_bad = (int)r[RED_BAD];
+    }
+    st->trials = trials0 + 1;
+    double lam = lam_same;                          // lambda of the step() below
     if (mode == MODE_INIT) {
         if (BOOK) { st->sweeps++; lm_trace(st, trace, err, -1.0, 2); }
         st->prev_err = err;
         if (!(fabs(err) < 1.0e300)) { st->status = -4; st->done = 1; return; }
     } else if (mode == MODE_EVAL) {
         if (BOOK) st->sweeps++;
-        if (err > st->prev_err && ++st->lambda_lg10 <= 16) {
+        if (err > prev_err && lam_lg + 1 <= 16) {
             // rejected: sweep the accepted point again with the larger lambda
+            lam_lg++;
+            st->lambda_lg10 = lam_lg;
             if (BOOK) { st->rejected++; lm_trace(st, trace, err, -1.0, 0); }
             st->mode = MODE_RESCHUR;
-            st->lg_partials = st->lambda_lg10;
-            st->lam_next = pow10_lg(st, st->lambda_lg10);
+            st->lg_partials = lam_lg;
+            st->lam_next = lam_up;
             return;
         }
-        st->lambda_lg10 = max(st->lambda_lg10 - 1, -16);
-        st->iters++;
-        double dnum = rs[RED_DNUM], dden = rs[RED_DDEN];
+        if (err > prev_err) lam_lg++;               // lambda already at 10^16: the ++ happened, OpenCV accepts the step
+        lam_lg = max(lam_lg - 1, -16);
+        st->lambda_lg10 = lam_lg;
+        st->iters = iters0 + 1;
+        double dnum = r[RED_DNUM], dden = r[RED_DDEN];
 #pragma unroll
         for (int a = 0; a < 9; a++) {
-            const double pa = st->intr_prev[a], ca = st->intr_cand[a];
-            const double d = ca - pa;
+            const double d = ic[a] - ip[a];
             dnum += d * d;
-            dden += pa * pa;
-            st->intr_prev[a] = ca;
+            dden += ip[a] * ip[a];
+            ip[a] = ic[a];
+            st->intr_prev[a] = ic[a];
         }
         // stop rule ||param - prevParam|| / ||prevParam|| < eps, decided without sqrt / divide
-        const bool small = dnum < st->eps * st->eps * dden;
+        const bool small = dnum < eps * eps * dden;
         st->parity ^= 1;
         st->prev_err = err;
         if (BOOK) {
@@ -143,15 +172,16 @@ __device__ __forceinline__ void lm_advance(LmState *st, const double *rs, TraceR
             lm_trace(st, trace, err, rel, 1);
         }
         if (!(fabs(err) < 1.0e300)) { st->status = -4; st->done = 1; return; }
-        if (st->iters >= st->max_iter || small) {
+        if (iters0 + 1 >= max_iter || small) {
             if (!small) st->status = 1;             // CCAL_W_MAX_ITER
             st->done = 1;
             return;
         }
-        if (st->lg_partials != st->lambda_lg10) {   // lambda saturated: partials are for another lambda
+        lam = pow10_sel(lam_lg);
+        if (lg_part != lam_lg) {                    // lambda saturated: partials are for another lambda
             st->mode = MODE_RESCHUR;
-            st->lg_partials = st->lambda_lg10;
-            st->lam_next = pow10_lg(st, st->lambda_lg10);
+            st->lg_partials = lam_lg;
+            st->lam_next = lam;
             return;
         }
     } else {
@@ -159,30 +189,31 @@ __device__ __forceinline__ void lm_advance(LmState *st, const double *rs, TraceR
     }
 
     // ---- step(): damped Schur system  S = A_l - SC = S0 + lambda diag(A),  rhs = g - sg  (row A8) ----
-    const double lam = pow10_lg(st, st->lambda_lg10);
+    STAMP2(0);
     double S[45], rhs[9], inv[9];
-    bool freep[9];
-#pragma unroll
-    for (int a = 0; a < 9; a++) freep[a] = st->mask[a] != 0 && rs[RED_DA + a] > 0.0;   // fixed / unobservable: delta = 0
 #pragma unroll
     for (int a = 0; a < 9; a++) {
 #pragma unroll
         for (int b = 0; b <= a; b++) {
-            double v = rs[RED_S + tri(a, b)];
-            if (a == b) v += lam * rs[RED_DA + a];
+            double v = r[RED_S + tri(a, b)];
+            if (a == b) v += lam * r[RED_DA + a];
             if (!(freep[a] && freep[b])) v = (a == b) ? 1.0 : 0.0;
             S[tri(a, b)] = v;
         }
-        rhs[a] = freep[a] ? rs[RED_GS + a] : 0.0;
+        rhs[a] = freep[a] ? r[RED_GS + a] : 0.0;
     }
+    STAMP2(1);
     const bool ok = chol_packed<9>(S, inv);
+    STAMP2(2);
     if (!ok) {
         // damped system not positive definite (degenerate geometry): damp harder
-        if (++st->lambda_lg10 <= 16) {
+        if (lam_lg + 1 <= 16) {
+            st->lambda_lg10 = lam_lg + 1;
             st->mode = MODE_RESCHUR;
-            st->lg_partials = st->lambda_lg10;
-            st->lam_next = pow10_lg(st, st->lambda_lg10);
+            st->lg_partials = lam_lg + 1;
+            st->lam_next = pow10_sel(lam_lg + 1);
         } else {
+            st->lambda_lg10 = lam_lg + 1;
             st->status = -3;
             st->done = 1;
         }
@@ -190,17 +221,21 @@ __device__ __forceinline__ void lm_advance(LmState *st, const double *rs, TraceR
     }
     fwd_subst<9>(S, inv, rhs);
     bwd_subst<9>(S, inv, rhs);
+    STAMP2(3);
+    double cand[9];
 #pragma unroll
     for (int a = 0; a < 9; a++) {
         const double d = freep[a] ? rhs[a] : 0.0;
         st->dint[a] = d;
-        st->intr_cand[a] = st->intr_prev[a] - d;
+        cand[a] = ip[a] - d;
     }
-    if (st->aspect > 0.0) st->intr_cand[0] = st->aspect * st->intr_cand[1];
+    if (aspect > 0.0) cand[0] = aspect * cand[1];
+#pragma unroll
+    for (int a = 0; a < 9; a++) st->intr_cand[a] = cand[a];
     st->lam_step = lam;
-    const int lgn = max(st->lambda_lg10 - 1, -16);
+    const int lgn = max(lam_lg - 1, -16);
     st->lg_partials = lgn;
-    st->lam_next = pow10_lg(st, lgn);
+    st->lam_next = pow10_sel(lgn);
     st->mode = MODE_EVAL;
 }
 
