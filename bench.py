@@ -250,7 +250,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic_bytes("ccal::k_lm_trial") if (N, P) == (1000, 54) else None,
-                         "kernel": "ccal::k_lm_trial", "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": "ccal::k_lm_trial<false>", "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": sweep_us, "launches_timed": n_timed,
                          "avg_launch_us_back_to_back": sweep_us_b2b,
                          "timed_region_with_events_ms_per_step": 1e3 * elapsed_events / args.steps},
