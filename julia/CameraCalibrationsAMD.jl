@@ -91,4 +91,31 @@ function unproject(c::Context, rowcol::Matrix{Float64}, f, cc, k, rvec, tvec, ch
     return out
 end
 
+# calculate_errors (src/buildcalibrations.jl:37-67) on the device.  objpoints [3,P] already scaled by
+# checker_size (:15), imgpoints [2,P,N] Float64, inv_pts [2,S,N] round-trip samples (the reference draws
+# them from the global RNG, :54; here the caller supplies them so the metric is reproducible).
+function calculate_errors(c::Context, n_corners, objpoints::Matrix{Float64}, imgpoints::Array{Float64,3}, f, cc, k,
+                          rvecs::Matrix{Float64}, tvecs::Matrix{Float64}, checker_size, inv_pts::Array{Float64,3})
+    N = size(imgpoints, 3); S = size(inv_pts, 2); out = zeros(Float64, 4)
+    check(ccall((:ccal_errors, LIB), Int32,
+                (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64,
+                 Ptr{Float64}, Ptr{Float64}, Float64, Int32, Ptr{Float64}, Ptr{Float64}),
+                c.h, N, n_corners[1], n_corners[2], objpoints, imgpoints, Float64[f...], Float64[cc...], Float64(k),
+                rvecs, tvecs, Float64(checker_size), S, inv_pts, out))
+    return (; n = N, reprojection = out[1], projection = out[2], distance = out[3], inverse = out[4])
+end
+
+# _detect_corners (src/detect_fit.jl:5-21) on the device: gray is the column-major Matrix{UInt8} of the image
+# (element (row, col) at gray[row + rows*col], i.e. stride_row = 1, stride_col = rows -- what the reference
+# hands to OpenCV, :7).  Returns `missing` or the n1 x n2 matrix of (row, col) corners, 0-based pixel centres.
+function detect_corners(c::Context, gray::Matrix{UInt8}, n_corners)
+    rows, cols = size(gray); n1, n2 = n_corners
+    corners = zeros(Float64, 2, n1 * n2); found = Ref{Int32}(0)
+    check(ccall((:ccal_detect_corners, LIB), Int32,
+                (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32, Int64, Int64, Int32, Int32, Ptr{Float64}, Ref{Int32}, Ptr{Float64}),
+                c.h, gray, rows, cols, 1, rows, n1, n2, corners, found, C_NULL))
+    found[] == 0 && return missing
+    return reshape([(corners[1, i], corners[2, i]) for i in 1:n1*n2], n1, n2)
+end
+
 end # module
