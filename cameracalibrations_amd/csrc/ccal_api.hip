@@ -464,6 +464,10 @@ static int finish_init(ccal_ctx *c, bool intr, bool extr) {
     HIPCHK(hipMemcpyAsync(h_intr, c->d_intr0, sizeof(double) * 9, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_flags, c->d_fail, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (via_p2p(c)) {              // a silent peer explains (and outranks) the NaN it left behind
+        std::string err;
+        if (c->p2p->check_and_clear(err)) return fail(CCAL_E_COMM, "ccal_init_intrinsics: " + err);
+    }
     if (intr) {
         if (c->h_flags[1] != 0) return fail(CCAL_E_DEGENERATE, "ccal_init_intrinsics: homography estimation failed");
         for (int a = 0; a < 9; a++) c->intr0[a] = h_intr[a];

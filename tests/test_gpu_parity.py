@@ -468,3 +468,51 @@ def test_sharded_fit_p2p_exchange_on_one_gpu(world, n_total):
     rv = np.vstack([np.array(out[r]["rvecs"]) for r in range(world)])
     tv = np.vstack([np.array(out[r]["tvecs"]) for r in range(world)])
     assert np.abs(rv - base["rvecs"]).max() < 1e-10 and np.abs(tv - base["tvecs"]).max() < 1e-9
+
+
+def _silent_peer_worker(rank, world, port, out):
+    import time
+
+    import torch
+    import torch.distributed as dist
+    from cameracalibrations_amd._ffi import CcalError
+    from cameracalibrations_amd.distributed import allgather_bytes_via_torch, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["CCAL_P2P_TIMEOUT_MS"] = "300"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        wl = syn.named_workload("C2", n_images=24)
+        lo, hi = shard_range(24, world, rank)
+        with Solver(0) as s:
+            s.set_problem(wl.obj, hi - lo, wl.image_size, aspect=wl.aspect, flags=wl.flags)
+            s.set_image_points(wl.img[lo:hi])
+            s.init_p2p(world, rank, 24, allgather_bytes_via_torch())
+            if rank == 0:                                  # rank 1 never sends a row
+                t0 = time.time()
+                try:
+                    s.calibrate()
+                    out[0] = dict(raised=False)
+                except CcalError as exc:
+                    out[0] = dict(raised=True, status=exc.code, seconds=time.time() - t0, msg=str(exc))
+            dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_p2p_silent_peer_times_out_instead_of_hanging():
+    """A rank whose peer never shows up must come back with CCAL_E_COMM after CCAL_P2P_TIMEOUT_MS: every
+    wait of the exchange kernels is bounded, nothing spins for good on the GPU."""
+    import socket
+
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_silent_peer_worker, args=(2, port, out), nprocs=2, join=True)
+    r = out[0]
+    assert r["raised"] and r["status"] == -6, r            # CCAL_E_COMM
+    assert r["seconds"] < 5.0 and "timed out" in r["msg"], r
