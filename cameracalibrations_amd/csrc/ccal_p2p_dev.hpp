@@ -33,19 +33,26 @@ __device__ inline bool p2p_exchange_rows(const P2PDev &p, unsigned int tag, int 
     if (tid < n) s_all[p.rank * P2P_MAX_DOUBLES + tid] = s_val[tid];
     bool ok = true;
     if (act) {
+        // all peers' words are requested together (one uncached round trip when the rows are already
+        // there, not one per peer); only the ones still missing are asked for again
         const long long t0 = wall_clock64();
         unsigned int *dst = reinterpret_cast<unsigned int *>(s_all);
-        for (int r = 0; r < p.world && ok; r++) {
-            if (r == p.rank) continue;
-            const unsigned long long *src = p.inbox + (base + r) * P2P_WORDS + w;
-            unsigned long long v;
-            while (true) {
-                v = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((unsigned int)(v >> 32) == tag) break;
-                if (wall_clock64() - t0 > p.budget) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            dst[r * (2 * P2P_MAX_DOUBLES) + w] = (unsigned int)v;   // little-endian halves of double w / 2
+        unsigned int pending = ((p.world >= 32 ? 0u : (1u << p.world)) - 1u) & ~(1u << p.rank);
+        while (pending != 0u) {
+            unsigned long long v[P2P_MAX_RANKS];
+#pragma unroll
+            for (int r = 0; r < P2P_MAX_RANKS; r++)
+                if (pending & (1u << r))
+                    v[r] = __hip_atomic_load(p.inbox + (base + r) * P2P_WORDS + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+            for (int r = 0; r < P2P_MAX_RANKS; r++)
+                if ((pending & (1u << r)) && (unsigned int)(v[r] >> 32) == tag) {
+                    dst[r * (2 * P2P_MAX_DOUBLES) + w] = (unsigned int)v[r];   // little-endian halves of double w / 2
+                    pending &= ~(1u << r);
+                }
+            if (pending == 0u) break;
+            if (wall_clock64() - t0 > p.budget) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(2);
         }
     }
     const int all_ok = __syncthreads_and(ok ? 1 : 0);
