@@ -466,29 +466,39 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
     double *red = s_red + wave * NRED;
 
     // ---- 2. block head of the accepted point -> wave-uniform registers ----
-    Hs[lane] = par ? h1a : h0a;
-    if (lane < 8) Hs[64 + lane] = par ? h1b : h0b;
-    wave_lds_sync();
+    // lane j holds head[j] (hsel) and lanes 0..7 head[64 + j] (hselb); uniform values are pulled out
+    // with v_readlane, no LDS staging of the head
+    const double hsel = par ? h1a : h0a, hselb = par ? h1b : h0b;
+    auto bcast = [](double v, int src) -> double {
+        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                                __builtin_amdgcn_readlane(__double2loint(v), src));
+    };
     double e6[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) e6[k] = Hs[BLK_EXT + k];    // LDS broadcast reads
+    for (int k = 0; k < 6; k++) e6[k] = bcast(hsel, BLK_EXT + k);
     double dnum = 0.0, dden = 0.0;
     double in[NINTR];
     if (mode == MODE_EVAL) {
-        // delta_i = C_l^-1 (h - B^T delta_int) = u_h - U_B delta_int, U kept by the last sweep
-        double d[6];
+        // delta_i = C_l^-1 (h - B^T delta_int) = u_h - U_B delta_int, U kept by the last sweep: lane
+        // 8 + 6a + k multiplies U[a][k] by delta_int[a]; the products (and u_h, head[62..67]) are
+        // transposed through LDS so that lane k < 6 adds up component k
+        static_assert(BLK_U == 8 && BLK_PD == 68, "head layout");
+        const bool isU = lane >= BLK_U && lane < BLK_U + 54;
+        const double da = isU ? ls.dint[(lane - BLK_U) / 6] : 1.0;
+        Hs[lane] = hsel * da;
+        if (lane < 4) Hs[64 + lane] = hselb;
+        wave_lds_sync();
+        double dl = 0.0;
+        if (lane < 6) {
+            double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < 6; k++) d[k] = Hs[BLK_U + 54 + k];
-#pragma unroll
-        for (int a = 0; a < NINTR; a++) {
-            const double da = ls.dint[a];
-#pragma unroll
-            for (int k = 0; k < 6; k++) d[k] -= Hs[BLK_U + a * 6 + k] * da;
+            for (int a = 0; a < NINTR; a++) acc += Hs[BLK_U + a * 6 + lane];
+            dl = Hs[BLK_U + 54 + lane] - acc;
         }
-        const bool ok = Hs[BLK_PD] != 0.0;
+        const bool ok = bcast(hselb, BLK_PD - 64) != 0.0;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            const double dk = ok ? d[k] : 0.0;    // degenerate view: leave its pose unchanged
+            const double dk = ok ? bcast(dl, k) : 0.0;    // degenerate view: leave its pose unchanged
             dden += e6[k] * e6[k];
             dnum += dk * dk;
             e6[k] -= dk;
