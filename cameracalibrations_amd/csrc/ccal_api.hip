@@ -245,6 +245,7 @@ int ccal_p2p_export(ccal_ctx *c, int32_t world_size, int32_t rank, char handle_o
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     delete c->p2p;
+    c->graph_dirty = true;             // a captured solve may hold the old inbox pointers
     c->p2p = new P2P();
     std::string err;
     if (c->p2p->create(world_size, rank, handle_out, err) != 0) {
