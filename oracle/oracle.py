@@ -36,7 +36,11 @@ class Stats(C.Structure):
 
 
 def build(force=False):
-    """Compile the oracle with gcc (recipe: oracle/Makefile)."""
+    """Compile the oracle with gcc (recipe: oracle/Makefile).  CCAL_ORACLE_ASAN=1 selects the
+    AddressSanitizer + UBSan build (`make asan`; run the tests with libasan preloaded)."""
+    if os.environ.get("CCAL_ORACLE_ASAN"):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "asan"])
+        return os.path.join(_HERE, "libccal_oracle_asan.so")
     so = os.path.join(_HERE, "libccal_oracle.so")
     src = os.path.join(_HERE, "ccal_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):

@@ -91,3 +91,30 @@ def test_sharded_step_equals_dense_step():
     delta[keep] = np.linalg.solve(A, Jte[keep])
     assert np.abs(np.array(d0) - delta[:9]).max() < 1e-9 * np.abs(delta[:9]).max()
     assert abs(e0 - sum(G[15, 15] for G in Gs)) < 1e-9 * e0
+
+
+def _handle_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = bytes([rank + 1]) * 64                       # stands in for a 64-byte hipIpcMemHandle_t
+        got = D.allgather_bytes_via_torch()(mine)
+        ident = D.broadcast_id_via_torch()(bytes(range(128)) if rank == 0 else None)
+        out[rank] = dict(handles=[bytes(h) for h in got], ident=bytes(ident))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_handle_exchange_helpers_world2():
+    """The bootstrap of both native transports: every rank's 64-byte inbox handle in rank order
+    (direct exchange) and rank 0's 128-byte id on every rank (RCCL)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_handle_worker, args=(2, port, out), nprocs=2, join=True)
+    for r in (0, 1):
+        assert out[r]["handles"] == [bytes([1]) * 64, bytes([2]) * 64]
+        assert out[r]["ident"] == bytes(range(128))
