@@ -85,6 +85,9 @@ SIGNATURES = {
     "ccal_calibrate": (C.c_int, [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_uint32,
                                  C.c_int32, C.c_double, C.c_int32, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int32),
                                  C.POINTER(Stats)]),
+    "ccal_calibrate_multi": (C.c_int, [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_uint32,
+                                       C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_int32), _dp, _dp, _dp, _dp, _dp,
+                                       C.POINTER(C.c_int32), C.POINTER(Stats)]),
     "ccal_thread_cleanup": (None, []),
     "ccal_project": (C.c_int, [C.c_void_p, _dp, C.c_int32, _dp, _dp, C.c_double, _dp, _dp, C.c_double, _dp]),
     "ccal_unproject": (C.c_int, [C.c_void_p, _dp, C.c_int32, _dp, _dp, C.c_double, _dp, _dp, C.c_double, _dp]),

@@ -102,6 +102,10 @@ struct ccal_ctx {
     double dbg_enqueue_s = 0, dbg_total_s = 0;
     int dbg_runs = 0;
     bool graph_dirty = true, use_graph = true, adaptive_batch = true, spin_wait = true;
+    // a solve in flight (lm_begin .. lm_end)
+    double run_t0 = 0;
+    long run_max_trials = 0, run_trials = 0;
+    bool run_graphed = false;
 };
 
 static void free_problem_buffers(ccal_ctx *c) {
@@ -624,22 +628,28 @@ static int capture_graph(ccal_ctx *c, hipGraphExec_t *out) {
     return CCAL_OK;
 }
 
-int ccal_lm_run(ccal_ctx *c) {
+// A solve in pieces, so that one host thread can drive several devices (ccal_calibrate_multi): their
+// kernels wait for each other's rows, hence every device's batch must be enqueued before any is waited for.
+//   lm_begin   first batch (one graph launch, or trial by trial) + terminating prologue-only launch
+//   lm_wait    until the batch has been consumed or the solve has ended
+//   lm_more    the graph was sized for another problem: another batch
+//   lm_end     books, errors, size of the next graph
+static int lm_begin(ccal_ctx *c) {
     if (!c) return fail(CCAL_E_ARG, "ccal_lm_run: ctx == NULL");
     if (!c->have_problem || !c->have_img || !c->have_intr || !c->have_ext)
         return fail(CCAL_E_STATE, "ccal_lm_run: initial intrinsics / extrinsics / image points not set");
     HIPCHK(hipSetDevice(c->device));
-    const double t0 = now_s();
+    c->run_t0 = now_s();
     // upper bound on trials: every accepted iteration may be preceded by lambda climbing
     // from -16 to 16 (rejections + re-damping sweeps)
-    long max_trials = 8L + (long)c->max_iter * 70L;
-    if (via_p2p(c) && max_trials > 65000L) max_trials = 65000L;   // the exchange tag carries the trial index in 16 bits
-    long trials = 0;
+    c->run_max_trials = 8L + (long)c->max_iter * 70L;
+    if (via_p2p(c) && c->run_max_trials > 65000L) c->run_max_trials = 65000L;   // the exchange tag carries the trial index in 16 bits
+    c->run_trials = 0;
     c->ev_used = 0;
     c->h_st->done = 0;
     *progress_word(c) = 0ull;
-    const bool graphed = c->use_graph && !c->time_sweeps && (!sharded(c) || via_p2p(c));
-    if (graphed) {
+    c->run_graphed = c->use_graph && !c->time_sweeps && (!sharded(c) || via_p2p(c));
+    if (c->run_graphed) {
         ccal_ctx::GraphKey key;
         memset(&key, 0, sizeof key);
         key.obj = c->d_obj; key.img = c->d_img; key.blk = c->d_blk; key.st = c->d_st; key.partials = c->d_partials;
@@ -653,30 +663,40 @@ int ccal_lm_run(ccal_ctx *c) {
         }
     }
     const double t_enq0 = now_s();
-    if (graphed) {
+    if (c->run_graphed) {
         HIPCHK(hipGraphLaunch(c->g_first, c->stream));
-        trials = c->lm_batch;
+        c->run_trials = c->lm_batch;
     } else {
         for (int k = 0; k < c->lm_batch; k++) {
             const int rc = enqueue_trial(c, c->stream, k, false);
             if (rc) return rc;
         }
-        trials = c->lm_batch;
-        const int rc = enqueue_trial(c, c->stream, (int)trials, true);
+        c->run_trials = c->lm_batch;
+        const int rc = enqueue_trial(c, c->stream, (int)c->run_trials, true);
         if (rc) return rc;
     }
     c->dbg_enqueue_s += now_s() - t_enq0;
-    int rc = wait_progress(c, trials);
-    if (rc) return rc;
-    // the graph was sized for another problem: continue trial by trial (the next solve re-captures)
-    while (!c->h_st->done && trials < max_trials) {
-        const int more = c->lm_batch < 4 ? 4 : c->lm_batch;
-        for (int k = 0; k < more; k++)
-            if ((rc = enqueue_trial(c, c->stream, (int)trials + k, false)) != CCAL_OK) return rc;
-        trials += more;
-        if ((rc = enqueue_trial(c, c->stream, (int)trials, true)) != CCAL_OK) return rc;
-        if ((rc = wait_progress(c, trials)) != CCAL_OK) return rc;
-    }
+    return CCAL_OK;
+}
+
+static int lm_wait(ccal_ctx *c) { return wait_progress(c, c->run_trials); }
+
+static bool lm_unfinished(const ccal_ctx *c) { return !c->h_st->done && c->run_trials < c->run_max_trials; }
+
+static int lm_more(ccal_ctx *c) {
+    HIPCHK(hipSetDevice(c->device));
+    int rc;
+    const int more = c->lm_batch < 4 ? 4 : c->lm_batch;
+    for (int k = 0; k < more; k++)
+        if ((rc = enqueue_trial(c, c->stream, (int)c->run_trials + k, false)) != CCAL_OK) return rc;
+    c->run_trials += more;
+    return enqueue_trial(c, c->stream, (int)c->run_trials, true);
+}
+
+static int lm_end(ccal_ctx *c) {
+    HIPCHK(hipSetDevice(c->device));
+    const bool graphed = c->run_graphed;
+    const double t0 = c->run_t0;
     if (via_p2p(c)) {
         std::string err;
         if (c->p2p->check_and_clear(err)) return fail(CCAL_E_COMM, "ccal_lm_run: " + err);
@@ -718,6 +738,17 @@ int ccal_lm_run(ccal_ctx *c) {
     if (r.status == -4) return fail(CCAL_E_NONFINITE, "ccal_lm_run: non-finite reprojection error on the device");
     if (r.status == -3) return fail(CCAL_E_DEGENERATE, "ccal_lm_run: reduced intrinsic system not positive definite");
     return r.status == 1 ? CCAL_W_MAX_ITER : CCAL_OK;
+}
+
+int ccal_lm_run(ccal_ctx *c) {
+    int rc = lm_begin(c);
+    if (rc) return rc;
+    if ((rc = lm_wait(c)) != CCAL_OK) return rc;
+    while (lm_unfinished(c)) {   // the graph was sized for another problem: continue (the next solve re-captures)
+        if ((rc = lm_more(c)) != CCAL_OK) return rc;
+        if ((rc = lm_wait(c)) != CCAL_OK) return rc;
+    }
+    return lm_end(c);
 }
 
 int ccal_set_sweep_timing(ccal_ctx *c, int32_t enable) {
@@ -792,8 +823,26 @@ int ccal_get_init(ccal_ctx *c, double intr[CCAL_NINTR], double *rt_host) {
 // stream, ~15 device buffers and the launch graph costs far more than a small fit.
 static thread_local ccal_ctx *t_cached[16] = {nullptr};
 
+// ... and one set of contexts per (host thread, device list) for ccal_calibrate_multi
+struct MultiSet {
+    std::vector<int> devices;
+    std::vector<ccal_ctx *> ctx;
+};
+static thread_local std::vector<MultiSet> t_multi;
+
+static void multi_destroy(MultiSet &m) {
+    // every inbox stays mapped until no context of the set can still be sending
+    for (ccal_ctx *c : m.ctx)
+        if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+    for (ccal_ctx *c : m.ctx)
+        if (c) ccal_destroy(c);
+    m.ctx.clear();
+}
+
 void ccal_thread_cleanup(void) {
     for (auto &c : t_cached) { if (c) ccal_destroy(c); c = nullptr; }
+    for (auto &m : t_multi) multi_destroy(m);
+    t_multi.clear();
 }
 
 int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int32_t width, int32_t height,
@@ -838,6 +887,116 @@ int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int
     if (rc < 0) {                  // leave no half-finished work behind on the cached stream
         const std::string keep = g_err;
         (void)hipStreamSynchronize(c->stream);
+        g_err = keep;
+    }
+    return rc;
+}
+
+static MultiSet *multi_get(int n_dev, const int32_t *dev_ids) {
+    std::vector<int> want(dev_ids, dev_ids + n_dev);
+    for (auto &m : t_multi)
+        if (m.devices == want) return &m;
+    MultiSet m;
+    m.devices = want;
+    m.ctx.assign(n_dev, nullptr);
+    bool ok = true;
+    for (int g = 0; g < n_dev && ok; g++) ok = ccal_create(dev_ids[g], &m.ctx[g]) == CCAL_OK;
+    std::vector<P2P *> boxes(n_dev, nullptr);
+    std::string err;
+    for (int g = 0; g < n_dev && ok; g++) {
+        ccal_ctx *c = m.ctx[g];
+        char unused[P2P_HANDLE_BYTES];
+        ok = hipSetDevice(c->device) == hipSuccess;
+        if (!ok) { fail(CCAL_E_DEVICE, "ccal_calibrate_multi: hipSetDevice failed"); break; }
+        c->p2p = new P2P();
+        if (c->p2p->create(n_dev, g, unused, err) != 0) { fail(CCAL_E_COMM, "ccal_calibrate_multi: " + err); ok = false; }
+        boxes[g] = c->p2p;
+    }
+    for (int g = 0; g < n_dev && ok; g++) {
+        if (m.ctx[g]->p2p->connect_local(boxes.data(), err) != 0) { fail(CCAL_E_COMM, "ccal_calibrate_multi: " + err); ok = false; }
+        m.ctx[g]->world = n_dev;
+        m.ctx[g]->rank = g;
+    }
+    if (!ok) {
+        const std::string keep = g_err;
+        multi_destroy(m);
+        g_err = keep;
+        return nullptr;
+    }
+    t_multi.push_back(m);
+    return &t_multi.back();
+}
+
+int ccal_calibrate_multi(const float *obj, const float *img, int32_t P, int32_t N, int32_t width, int32_t height,
+                         double aspect, uint32_t flags, int32_t max_iter, double eps, int32_t n_dev,
+                         const int32_t *dev_ids, double K4[4], double dist5[5], double *rvecs, double *tvecs,
+                         double *rms, int32_t *iters, ccal_stats *stats) {
+    if (!obj || !img || !dev_ids) return fail(CCAL_E_ARG, "ccal_calibrate_multi: NULL argument");
+    if (n_dev < 1 || n_dev > P2P_MAX_RANKS) return fail(CCAL_E_ARG, "ccal_calibrate_multi: 1..16 devices");
+    if (N < n_dev) return fail(CCAL_E_ARG, "ccal_calibrate_multi: fewer images than devices");
+    for (int g = 0; g < n_dev; g++)
+        if (dev_ids[g] < 0 || dev_ids[g] >= 16) return fail(CCAL_E_ARG, "ccal_calibrate_multi: bad device id");
+    MultiSet *m = multi_get(n_dev, dev_ids);
+    if (!m) return CCAL_E_COMM;
+    const bool guess = (flags & CCAL_USE_INTRINSIC_GUESS) != 0;
+    if (guess && (!K4 || !dist5)) return fail(CCAL_E_ARG, "ccal_calibrate_multi: intrinsic guess requested but K4/dist5 NULL");
+    std::vector<int> lo(n_dev + 1, 0);
+    for (int g = 0; g < n_dev; g++) lo[g + 1] = lo[g] + N / n_dev + (g < N % n_dev ? 1 : 0);   // contiguous shards
+    int rc = CCAL_OK, lm_rc = CCAL_OK;
+    std::string lm_err;
+    // every stage is enqueued on ALL devices before anything waits: the devices' kernels wait for each other's rows
+    for (ccal_ctx *c : m->ctx) c->defer_sync = true;
+    do {
+        for (int g = 0; g < n_dev && rc >= 0; g++) {
+            ccal_ctx *c = m->ctx[g];
+            c->n_global = N;
+            if ((rc = ccal_set_problem(c, obj, P, lo[g + 1] - lo[g], width, height, aspect, flags, max_iter, eps)) < 0) break;
+            if ((rc = ccal_set_image_points(c, img + (size_t)lo[g] * 2 * P)) < 0) break;
+            if (guess) {
+                const double gs[9] = {K4[0], K4[1], K4[2], K4[3], dist5[0], dist5[1], dist5[2], dist5[3], dist5[4]};
+                rc = ccal_set_intrinsics(c, gs);
+            }
+        }
+        if (rc < 0) break;
+        if (!guess)
+            for (int g = 0; g < n_dev && rc >= 0; g++) rc = ccal_init_intrinsics(m->ctx[g]);
+        for (int g = 0; g < n_dev && rc >= 0; g++) rc = ccal_init_extrinsics(m->ctx[g]);
+        for (int g = 0; g < n_dev && rc >= 0; g++) rc = lm_begin(m->ctx[g]);
+        for (int g = 0; g < n_dev && rc >= 0; g++) rc = lm_wait(m->ctx[g]);
+        while (rc >= 0 && lm_unfinished(m->ctx[0])) {   // identical state on every device: one decision for all
+            for (int g = 0; g < n_dev && rc >= 0; g++) rc = lm_more(m->ctx[g]);
+            for (int g = 0; g < n_dev && rc >= 0; g++) rc = lm_wait(m->ctx[g]);
+        }
+        if (rc < 0) break;
+        for (int g = 0; g < n_dev; g++) {
+            const int e = lm_end(m->ctx[g]);
+            if (g == 0 || (e < 0 && lm_rc >= 0)) { lm_rc = e; lm_err = g_err; }
+        }
+        // initialisation failures explain (and outrank) whatever the LM reported on garbage
+        for (int g = 0; g < n_dev && rc >= 0; g++) rc = finish_init(m->ctx[g], !guess, true);
+        if (rc < 0) break;
+        if ((rc = lm_rc) < 0) { g_err = lm_err; break; }
+        double intr[9];
+        ccal_stats st;
+        for (int g = 0; g < n_dev && rc >= 0; g++) {
+            ccal_stats sg;
+            rc = ccal_get_result(m->ctx[g], g == 0 ? intr : nullptr, rvecs ? rvecs + (size_t)3 * lo[g] : nullptr,
+                                 tvecs ? tvecs + (size_t)3 * lo[g] : nullptr, &sg);
+            if (g == 0) st = sg;
+        }
+        if (rc < 0) break;
+        if (K4) memcpy(K4, intr, sizeof(double) * 4);
+        if (dist5) memcpy(dist5, intr + 4, sizeof(double) * 5);
+        if (rms) *rms = st.rms;
+        if (iters) *iters = st.iters;
+        if (stats) *stats = st;
+        rc = lm_rc;
+    } while (0);
+    for (ccal_ctx *c : m->ctx) c->defer_sync = false;
+    if (rc < 0) {                  // leave no half-finished work behind on the cached streams
+        const std::string keep = g_err;
+        for (ccal_ctx *c : m->ctx) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+        for (ccal_ctx *c : m->ctx) { std::string e; if (c->p2p) (void)c->p2p->check_and_clear(e); }
         g_err = keep;
     }
     return rc;

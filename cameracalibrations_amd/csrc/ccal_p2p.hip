@@ -25,7 +25,7 @@ P2P::~P2P() {
     (void)hipSetDevice(device_);
     (void)hipDeviceSynchronize();
     for (int r = 0; r < dev_.world; r++)
-        if (connected_ && r != dev_.rank && dev_.peer[r]) (void)hipIpcCloseMemHandle(dev_.peer[r]);
+        if (connected_ && ipc_ && r != dev_.rank && dev_.peer[r]) (void)hipIpcCloseMemHandle(dev_.peer[r]);
     (void)hipFree(dev_.inbox);
     (void)hipFree(dev_.epoch);
     (void)hipHostFree(dev_.err);
@@ -73,6 +73,29 @@ int P2P::connect(const char *handles, std::string &err) {
         dev_.peer[r] = static_cast<unsigned long long *>(p);
     }
     connected_ = true;
+    ipc_ = true;
+    return 0;
+}
+
+int P2P::connect_local(P2P *const *peers, std::string &err) {
+    if (!created_) { err = "P2P::connect_local before create"; return -1; }
+    if (connected_) { err = "P2P::connect_local called twice"; return -1; }
+    P2PCHK(hipSetDevice(device_));
+    for (int r = 0; r < dev_.world; r++) {
+        if (r == dev_.rank) continue;
+        if (!peers[r] || !peers[r]->created_) { err = "P2P::connect_local: peer inbox missing"; return -1; }
+        if (peers[r]->device_ != device_) {
+            int can = 0;
+            P2PCHK(hipDeviceCanAccessPeer(&can, device_, peers[r]->device_));
+            if (!can) { err = "P2P::connect_local: no peer access between the devices"; return -1; }
+            const hipError_t e = hipDeviceEnablePeerAccess(peers[r]->device_, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { err = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); return -1; }
+            (void)hipGetLastError();
+        }
+        dev_.peer[r] = peers[r]->dev_.inbox;
+    }
+    connected_ = true;
+    ipc_ = false;
     return 0;
 }
 

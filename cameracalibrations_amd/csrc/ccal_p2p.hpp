@@ -54,6 +54,9 @@ class P2P {
     int create(int world, int rank, char handle_out[P2P_HANDLE_BYTES], std::string &err);
     // map the peers' inboxes; handles = world x 64 bytes in rank order (own entry ignored)
     int connect(const char *handles, std::string &err);
+    // same process, one context per device: the peers' inboxes are plain device pointers (peer access
+    // between different devices is switched on here); peers[r] for every rank r, own entry ignored
+    int connect_local(P2P *const *peers, std::string &err);
     bool ready() const { return connected_; }
     int world() const { return dev_.world; }
     int rank() const { return dev_.rank; }
@@ -63,7 +66,7 @@ class P2P {
 
   private:
     P2PDev dev_{};
-    bool created_ = false, connected_ = false;
+    bool created_ = false, connected_ = false, ipc_ = false;
     int device_ = 0;
 };
 

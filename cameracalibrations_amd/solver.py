@@ -213,6 +213,28 @@ def reference_flags(with_distortion=True):
 CRITERIA = (30, 0.001)   # TermCriteria(EPS + MAX_ITER, 30, 0.001), src/CameraCalibrations.jl:16
 
 
+def calibrate_multi(obj, img, image_size, devices, aspect=1.0, flags=0, max_iter=CRITERIA[0], eps=CRITERIA[1]):
+    """One fit over several GPUs from this one host thread (ccal_calibrate_multi): images are sharded
+    contiguously over `devices`.  obj (P,3), img (N,P,2) host arrays -> (status, dict like Solver.result())."""
+    obj, op = F.f32(obj)
+    img, ip = F.f32(img)
+    N, P = img.shape[0], obj.shape[0]
+    assert img.shape == (N, P, 2)
+    devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+    K4, dist5 = np.zeros(4), np.zeros(5)
+    rv, tv = np.zeros((N, 3)), np.zeros((N, 3))
+    rms, iters = C.c_double(0), C.c_int32(0)
+    st = F.Stats()
+    dp = F._dp
+    status = F.check(F.lib().ccal_calibrate_multi(op, ip, P, N, int(image_size[0]), int(image_size[1]), float(aspect),
+                                                  int(flags), int(max_iter), float(eps), len(devices), devs,
+                                                  K4.ctypes.data_as(dp), dist5.ctypes.data_as(dp), rv.ctypes.data_as(dp),
+                                                  tv.ctypes.data_as(dp), C.byref(rms), C.byref(iters), C.byref(st)))
+    d = st.asdict()
+    d.update(intr=np.r_[K4, dist5], rvecs=rv, tvecs=tv, rms=rms.value, iters=iters.value)
+    return status, d
+
+
 def fit_model(sz, objpoints, imgpointss, n_corners, with_distortion, aspect, device=0):
     """Drop-in for the reference's `fit_model` (src/detect_fit.jl:27-61).
 

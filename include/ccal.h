@@ -170,6 +170,18 @@ int  ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, in
                     int32_t device, double K4[4], double dist5[5], double *rvecs, double *tvecs,
                     double *rms, int32_t *iters, ccal_stats *stats);
 
+/* The same call over several GPUs of one node from ONE host thread (the form a Julia caller wants:
+ * SURVEY.md 8b `n_dev, dev_ids`): images are sharded contiguously over dev_ids[0..n_dev), every device
+ * runs the same kernels as in the one-process-per-GPU form and the reduced intrinsic system travels by
+ * the direct xGMI row exchange (the inboxes are plain peer-mapped pointers here, no IPC).  Every stage
+ * is enqueued on all devices before the host waits for any.  img / rvecs / tvecs are the full [.,.,N] /
+ * [3,N] host arrays; results are identical on every device and taken from dev_ids[0].  1..16 devices,
+ * N >= n_dev; a device id may appear more than once (two shards on one GPU; used by the tests). */
+int  ccal_calibrate_multi(const float *obj, const float *img, int32_t P, int32_t N, int32_t width,
+                          int32_t height, double aspect, uint32_t flags, int32_t max_iter, double eps,
+                          int32_t n_dev, const int32_t *dev_ids, double K4[4], double dist5[5],
+                          double *rvecs, double *tvecs, double *rms, int32_t *iters, ccal_stats *stats);
+
 /* ccal_calibrate keeps one context per (host thread, device) alive between calls (creating a
  * stream, the device buffers and the launch graph costs more than a small fit); this frees the
  * calling thread's cached contexts. */

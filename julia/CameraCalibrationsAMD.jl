@@ -39,7 +39,7 @@ Same contract as the reference wrapper of `OpenCV.calibrateCamera`: `objpoints` 
 n1 x n2 x 1 template of XYZ, `imgpointss` a vector of n1 x n2 matrices of RowCol, `sz` the
 size of the Julia image (== OpenCV (width, height), src/detect_fit.jl:32).
 """
-function fit_model(sz, objpoints, imgpointss, n_corners, with_distortion, aspect; device = 0)
+function fit_model(sz, objpoints, imgpointss, n_corners, with_distortion, aspect; device = 0, devices = nothing)
     P = prod(n_corners)
     N = length(imgpointss)
     obj = Float32.(reshape(reinterpret(reshape, eltype(eltype(objpoints)), vec(objpoints)), 3, P))   # [3,P]
@@ -51,11 +51,20 @@ function fit_model(sz, objpoints, imgpointss, n_corners, with_distortion, aspect
     K4 = zeros(Float64, 4); dist = zeros(Float64, 5)
     rvecs = zeros(Float64, 3, N); tvecs = zeros(Float64, 3, N)
     rms = Ref{Float64}(0); iters = Ref{Int32}(0)
+    if devices !== nothing      # several GPUs of the node from this one task: images sharded over `devices`
+        devs = Int32.(collect(devices))
+        check(ccall((:ccal_calibrate_multi, LIB), Int32,
+                    (Ptr{Float32}, Ptr{Float32}, Int32, Int32, Int32, Int32, Float64, UInt32, Int32, Float64, Int32, Ptr{Int32},
+                     Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Int32}, Ptr{Cvoid}),
+                    obj, img, P, N, sz[1], sz[2], Float64(aspect), flags, CRITERIA[1], CRITERIA[2], length(devs), devs,
+                    K4, dist, rvecs, tvecs, rms, iters, C_NULL))
+    else
     check(ccall((:ccal_calibrate, LIB), Int32,
                 (Ptr{Float32}, Ptr{Float32}, Int32, Int32, Int32, Int32, Float64, UInt32, Int32, Float64, Int32,
                  Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Int32}, Ptr{Cvoid}),
                 obj, img, P, N, sz[1], sz[2], Float64(aspect), flags, CRITERIA[1], CRITERIA[2], device,
                 K4, dist, rvecs, tvecs, rms, iters, C_NULL))
+    end
     k = dist[1]
     Rs = [rvecs[:, i] for i in 1:N]
     ts = [tvecs[:, i] for i in 1:N]

@@ -516,3 +516,23 @@ def test_p2p_silent_peer_times_out_instead_of_hanging():
     r = out[0]
     assert r["raised"] and r["status"] == -6, r            # CCAL_E_COMM
     assert r["seconds"] < 5.0 and "timed out" in r["msg"], r
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+def test_calibrate_multi_single_host_thread(devices):
+    """ccal_calibrate_multi: one host thread drives one context per listed device (here the test box's
+    one GPU, listed up to three times = up to three shards whose kernels wait for each other's rows through
+    in-process peer pointers).  The joint fit equals the single-context fit of all images, twice in a row
+    (cached contexts, graph replay), and the per-image poses come back in image order."""
+    from cameracalibrations_amd.solver import calibrate_multi
+    wl = syn.named_workload("C2", n_images=41)
+    with _solver(wl, REF) as s:
+        _, base = s.calibrate()
+    for rep in range(2):
+        st, r = calibrate_multi(wl.obj, wl.img, wl.image_size, devices, aspect=wl.aspect, flags=wl.flags)
+        assert st == 0 and r["iters"] == base["iters"] and r["sweeps"] == base["sweeps"]
+        assert abs(r["rms"] - base["rms"]) < 1e-12
+        assert np.abs(r["intr"] - base["intr"]).max() < 1e-9 * base["intr"][1]
+        assert np.abs(r["rvecs"] - base["rvecs"]).max() < 1e-10 and np.abs(r["tvecs"] - base["tvecs"]).max() < 1e-9
+    from cameracalibrations_amd import _ffi
+    _ffi.lib().ccal_thread_cleanup()
