@@ -116,6 +116,9 @@ static void free_problem_buffers(ccal_ctx *c) {
     c->img_cap = 0; c->n_cap = 0; c->p_cap = 0;
 }
 
+static thread_local bool t_stream_priority_set = false;
+static thread_local int t_stream_priority = 0;
+
 extern "C" {
 
 int ccal_version(void) { return CCAL_VERSION; }
@@ -147,7 +150,14 @@ int ccal_create(int device, ccal_ctx **out) {
     HIPCHK(hipSetDevice(device));
     ccal_ctx *c = new ccal_ctx();
     c->device = device;
-    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    if (t_stream_priority_set) {
+        // ccal_calibrate_multi with one device listed more than once: the shards' kernels wait for each
+        // other, so their streams must not end up in the same hardware queue (a queue runs in order);
+        // streams of different priority never share one
+        HIPCHK(hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, t_stream_priority));
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    }
     c->stream = c->own_stream;
     HIPCHK(hipMalloc(&c->d_st, sizeof(LmState) * 2));          // S_k lives in d_st[k & 1]
     HIPCHK(hipMalloc(&c->d_st_scratch, sizeof(LmState) * 2));
@@ -900,7 +910,23 @@ static MultiSet *multi_get(int n_dev, const int32_t *dev_ids) {
     m.devices = want;
     m.ctx.assign(n_dev, nullptr);
     bool ok = true;
-    for (int g = 0; g < n_dev && ok; g++) ok = ccal_create(dev_ids[g], &m.ctx[g]) == CCAL_OK;
+    for (int g = 0; g < n_dev && ok; g++) {
+        int dup = 0;
+        for (int h = 0; h < g; h++) dup += dev_ids[h] == dev_ids[g];
+        if (dup > 0) {
+            int least = 0, greatest = 0;
+            ok = hipSetDevice(dev_ids[g]) == hipSuccess && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+            if (!ok || dup > 2 || least == greatest) {
+                fail(CCAL_E_ARG, "ccal_calibrate_multi: a device can be listed at most three times (one stream priority each)");
+                ok = false;
+                break;
+            }
+            t_stream_priority_set = true;
+            t_stream_priority = dup == 1 ? greatest : least;
+        }
+        ok = ccal_create(dev_ids[g], &m.ctx[g]) == CCAL_OK;
+        t_stream_priority_set = false;
+    }
     std::vector<P2P *> boxes(n_dev, nullptr);
     std::string err;
     for (int g = 0; g < n_dev && ok; g++) {

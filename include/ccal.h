@@ -176,7 +176,8 @@ int  ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, in
  * the direct xGMI row exchange (the inboxes are plain peer-mapped pointers here, no IPC).  Every stage
  * is enqueued on all devices before the host waits for any.  img / rvecs / tvecs are the full [.,.,N] /
  * [3,N] host arrays; results are identical on every device and taken from dev_ids[0].  1..16 devices,
- * N >= n_dev; a device id may appear more than once (two shards on one GPU; used by the tests). */
+ * N >= n_dev; a device id may appear up to three times (shards on one GPU, each on a stream of its own
+ * priority so that they never share an in-order hardware queue; used by the tests). */
 int  ccal_calibrate_multi(const float *obj, const float *img, int32_t P, int32_t N, int32_t width,
                           int32_t height, double aspect, uint32_t flags, int32_t max_iter, double eps,
                           int32_t n_dev, const int32_t *dev_ids, double K4[4], double dist5[5],
