@@ -536,3 +536,39 @@ def test_calibrate_multi_single_host_thread(devices):
         assert np.abs(r["rvecs"] - base["rvecs"]).max() < 1e-10 and np.abs(r["tvecs"] - base["tvecs"]).max() < 1e-9
     from cameracalibrations_amd import _ffi
     _ffi.lib().ccal_thread_cleanup()
+
+
+def test_c_abi_from_plain_c(golden_dir, tmp_path):
+    """The boundary is a C ABI, not a Python extension: examples/fit_from_c.c (gcc, include/ccal.h, linked
+    against libccal_hip.so only -- no Python, no torch in that process) fits the reference's example corners
+    and must print exactly what the Python mirror's `fit_model` returns from the same library."""
+    import shutil
+    import struct
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "cameracalibrations_amd")
+    exe = str(tmp_path / "fit_from_c")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "fit_from_c.c"), "-o", exe, "-L" + libdir, "-lccal_hip",
+                           "-Wl,-rpath," + libdir, "-lm"])
+    ex = json.load(open(os.path.join(golden_dir, "example_corners.json")))
+    n_corners = tuple(ex["n_corners"])
+    P = n_corners[0] * n_corners[1]
+    img = np.array(ex["corners"], dtype=np.float32).reshape(-1, P, 2)
+    obj = syn.board_template(n_corners).astype(np.float32)
+    w, h = ex["image_size_wh"]
+    path = tmp_path / "corners.bin"
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<4i", P, img.shape[0], int(w), int(h)))
+        fh.write(obj.tobytes())
+        fh.write(img.tobytes())
+    out = subprocess.run([exe, str(path), "1", "1.0"], check=True, capture_output=True, text=True, timeout=120).stdout.split("\n")
+    head = out[0].split()
+    vals = dict(zip(out[1].split()[0::2], map(float, out[1].split()[1::2])))
+    m = fit_model((w, h), obj, list(img), n_corners, True, 1.0)
+    assert int(head[1]) == 0 and int(head[3]) == m.iters and float(head[5]) == m.rms
+    assert (vals["frow"], vals["fcol"], vals["crow"], vals["ccol"], vals["k"]) == (m.frow, m.fcol, m.crow, m.ccol, m.k)
+    poses = np.array([[float(x) for x in ln.split()[1:4] + ln.split()[5:8]] for ln in out[2:2 + img.shape[0]]])
+    assert np.array_equal(poses[:, :3], np.array(m.Rs)) and np.array_equal(poses[:, 3:], np.array(m.ts))
