@@ -54,3 +54,18 @@ def test_product_never_imports_oracle():
 def test_struct_layouts_match_header():
     assert C.sizeof(F.Trace) == 32
     assert C.sizeof(F.Stats) == 6 * 8 + 8 * 4 + 8
+
+
+def test_plain_c_example_compiles_and_links(tmp_path):
+    """include/ccal.h is valid C99 and examples/fit_from_c.c links against the shared library alone."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "cameracalibrations_amd")
+    from cameracalibrations_amd import build
+    build.build()
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "fit_from_c.c"), "-o", str(tmp_path / "fit_from_c"),
+                           "-L" + libdir, "-lccal_hip", "-Wl,-rpath," + libdir, "-lm"])
