@@ -572,3 +572,36 @@ def test_c_abi_from_plain_c(golden_dir, tmp_path):
     assert (vals["frow"], vals["fcol"], vals["crow"], vals["ccol"], vals["k"]) == (m.frow, m.fcol, m.crow, m.ccol, m.k)
     poses = np.array([[float(x) for x in ln.split()[1:4] + ln.split()[5:8]] for ln in out[2:2 + img.shape[0]]])
     assert np.array_equal(poses[:, :3], np.array(m.Rs)) and np.array_equal(poses[:, 3:], np.array(m.ts))
+
+
+RANDOM_CASES = [
+    # (seed, n_corners, n_images, model, flags, sigma, depth)
+    (1, (5, 8), 5, "ref", syn.FIX_ASPECT_RATIO | syn.ZERO_TANGENT_DIST | syn.FIX_K2 | syn.FIX_K3, 0.05, (8.0, 16.0)),
+    (2, (9, 6), 23, "k1k2p1p2", syn.FIX_K3, 0.2, (8.0, 16.0)),
+    (3, (7, 7), 9, "pinhole", syn.ZERO_TANGENT_DIST | syn.FIX_K1 | syn.FIX_K2 | syn.FIX_K3, 0.3, (8.0, 16.0)),
+    (4, (15, 10), 7, "full", 0, 0.1, (14.0, 28.0)),                      # 150 corners: three 64-corner passes per image
+    (5, (11, 4), 31, "k1k2p1p2", syn.FIX_K3 | syn.FIX_K2, 0.0, (8.0, 16.0)),  # noise-free (only Float32 rounding)
+    (6, (9, 6), 3, "ref", syn.FIX_ASPECT_RATIO | syn.ZERO_TANGENT_DIST | syn.FIX_K1 | syn.FIX_K2 | syn.FIX_K3, 0.1, (8.0, 16.0)),
+    (7, (13, 5), 12, "k1k2p1p2", syn.FIX_K3 | syn.FIX_PRINCIPAL_POINT, 0.15, (10.0, 20.0)),
+    (8, (6, 5), 64, "full", syn.FIX_K3, 0.1, (8.0, 16.0)),
+]
+
+
+@pytest.mark.parametrize("seed,n_corners,n_images,model,flags,sigma,depth", RANDOM_CASES)
+def test_random_problems_match_oracle(seed, n_corners, n_images, model, flags, sigma, depth):
+    """Seeded problems of assorted board shapes (incl. multi-pass 150-corner images), image counts, models,
+    flag words and noise levels: full fit (device init + LM, OpenCV's criteria) against the oracle --
+    same accepted-iteration count, RMS to 1e-8 px, parameters to 1e-6 relative / 1e-5."""
+    wl = syn.make_workload("rnd", n_corners, n_images, model, seed=1000 + seed, sigma=sigma, depth=depth, aspect=1.0)
+    aspect = 1.0
+    ro = orc.calibrate(wl.obj, wl.img, wl.image_size, aspect=aspect, flags=flags, max_iter=30, eps=1e-3, solver="schur")
+    with Solver(0) as s:
+        s.set_problem(wl.obj, wl.n_images, wl.image_size, aspect=aspect, flags=flags, max_iter=30, eps=1e-3)
+        s.set_image_points(wl.img)
+        st, r = s.calibrate()
+    assert st in (0, 1)
+    assert r["iters"] == ro["iters"], (r["iters"], ro["iters"])
+    assert abs(r["rms"] - ro["rms"]) < 1e-8
+    assert np.abs(r["intr"][:4] - ro["intr"][:4]).max() / ro["intr"][1] < 1e-6
+    assert np.abs(r["intr"][4:] - ro["intr"][4:]).max() < 1e-5
+    assert np.abs(r["rvecs"] - ro["rvecs"]).max() < 1e-5 and np.abs(r["tvecs"] - ro["tvecs"]).max() < 1e-4
