@@ -16,7 +16,9 @@ SOURCES = ["ccal_lm.hip", "ccal_init.hip", "ccal_maps.hip", "ccal_comm.hip", "cc
 HEADERS = ["ccal_math.hpp", "ccal_state.hpp", "ccal_wave.hpp", "ccal_kernels.hpp", "ccal_comm.hpp", "ccal_p2p.hpp", "ccal_p2p_dev.hpp", "ccal_detect.hpp",
            "../../include/ccal.h"]
 LIB = os.path.join(HERE, "libccal_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"]
+# max-ilp: the hot kernels run one wave per SIMD, so the scheduler should hide FP64 latency inside the wave
+# rather than save registers for occupancy (measured: 10.8 -> 10.45 us per k_lm_trial launch)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
 def _stale(target, deps):

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "cameracalibrations_amd", "csrc")
 OUT = "/tmp/libccal_hip_stamps.so"
 srcs = [os.path.join(CSRC, f) for f in ("ccal_lm.hip", "ccal_init.hip", "ccal_maps.hip", "ccal_comm.hip", "ccal_p2p.hip", "ccal_detect.hip", "ccal_api.hip")]
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
                        "-DCCAL_STAMPS", "-o", OUT, *srcs, "-ldl"])
 from cameracalibrations_amd import _ffi as F  # noqa: E402
 F.LIB_PATH = OUT
