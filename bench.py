@@ -251,6 +251,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic_bytes("ccal::k_lm_trial") if (N, P) == (1000, 54) else None,
                          "kernel": "ccal::k_lm_trial<false>", "algorithmic_bytes_per_launch": alg_bytes,
+                         # SURVEY.md 8d diagnostic: the same sweep with the per-image blocks kept in HBM (this design)
+                         "bytes_per_launch_with_blocks_in_hbm": alg_bytes + N * 2 * 8 * (27 + 6 * 8) if P == 54 else None,
                          "avg_launch_us": sweep_us, "launches_timed": n_timed,
                          "avg_launch_us_back_to_back": sweep_us_b2b,
                          "timed_region_with_events_ms_per_step": 1e3 * elapsed_events / args.steps},
