@@ -8,7 +8,7 @@ mkdir -p gpurun_out/pmc
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/pmc_calib tools/pmc_calib.hip
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc/$ctr gpurun_out/pmc/calib_$ctr
-  timeout -k 10 200 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc/$ctr -o pmc -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline > gpurun_out/pmc/bench_$ctr.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc/$ctr -o pmc -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --timed-only > gpurun_out/pmc/bench_$ctr.log 2>&1
   timeout -k 10 100 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/pmc/calib_$ctr -o pmc -- /tmp/pmc_calib > gpurun_out/pmc/calib_$ctr.log 2>&1
 done
 python3 tools/pmc_summary.py

@@ -7,7 +7,7 @@ mkdir -p gpurun_out/pmc_util
 run() { # name, counters...
   local name=$1; shift
   rm -rf gpurun_out/pmc_util/$name
-  timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc_util/$name -o pmc -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline > gpurun_out/pmc_util/bench_$name.log 2>&1 || echo "pass $name failed"
+  timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc_util/$name -o pmc -- python3 bench.py --steps 20 --warmup 2 --no-cpu-baseline --timed-only > gpurun_out/pmc_util/bench_$name.log 2>&1 || echo "pass $name failed"
 }
 run a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES
 run b SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_ANY
