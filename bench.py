@@ -114,9 +114,9 @@ def main():
     N, P = wl.n_images, wl.n_points
     img_dev = torch.from_numpy(wl.img).to(dev)                      # inputs resident in HBM
     torch.cuda.synchronize()
-    stream = torch.cuda.current_stream().cuda_stream
-
-    s = Solver(local_rank, stream=stream)
+    # the context's own non-blocking stream (not torch's legacy default stream, which serialises with every
+    # blocking stream of the process): the timed region is bracketed by device-wide synchronisation anyway
+    s = Solver(local_rank)
     s.set_problem(wl.obj, N, wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=CRITERIA[0], eps=CRITERIA[1])
     s.set_image_points(img_dev)
 
