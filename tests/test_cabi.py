@@ -69,3 +69,29 @@ def test_plain_c_example_compiles_and_links(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
                            os.path.join(root, "examples", "fit_from_c.c"), "-o", str(tmp_path / "fit_from_c"),
                            "-L" + libdir, "-lccal_hip", "-Wl,-rpath," + libdir, "-lm"])
+
+
+def test_argument_checks_need_no_device(lib):
+    """Bad arguments of the multi-device and exchange entry points are refused before any HIP call; without
+    a GPU the multi-device fit fails like the single-device one (no CPU path)."""
+    import numpy as np
+    from cameracalibrations_amd.solver import calibrate_multi
+    obj = np.zeros((54, 3), np.float32)
+    img = np.zeros((4, 54, 2), np.float32)
+    with pytest.raises(F.CcalError) as e:
+        calibrate_multi(obj, img, (1500, 2000), [])                   # no devices
+    assert e.value.code == -1
+    with pytest.raises(F.CcalError) as e:
+        calibrate_multi(obj, img, (1500, 2000), [0] * 5)              # more devices than images
+    assert e.value.code == -1
+    with pytest.raises(F.CcalError) as e:
+        calibrate_multi(obj, img, (1500, 2000), [99])                 # device id out of range
+    assert e.value.code == -1
+    assert lib.ccal_p2p_export(None, 2, 0, C.create_string_buffer(64)) == -1
+    assert lib.ccal_p2p_connect(None, b"\0" * 128, 8) == -1
+    assert lib.ccal_p2p_selftest(None, 4) == -1
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(F.CcalError) as e:
+            calibrate_multi(obj, img, (1500, 2000), [0, 1])
+        assert e.value.code == F.E_DEVICE or e.value.code == -6

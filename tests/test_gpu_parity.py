@@ -605,3 +605,12 @@ def test_random_problems_match_oracle(seed, n_corners, n_images, model, flags, s
     assert np.abs(r["intr"][:4] - ro["intr"][:4]).max() / ro["intr"][1] < 1e-6
     assert np.abs(r["intr"][4:] - ro["intr"][4:]).max() < 1e-5
     assert np.abs(r["rvecs"] - ro["rvecs"]).max() < 1e-5 and np.abs(r["tvecs"] - ro["tvecs"]).max() < 1e-4
+
+
+def test_p2p_selftest_world1():
+    """ccal_p2p_selftest on a one-rank exchange (own inbox only): the stand-alone all-reduce kernel, sequence
+    numbers advancing on the device, known sums back on the host."""
+    with Solver(0) as s:
+        s.init_p2p(1, 0, 8, lambda b: [b])
+        s.p2p_selftest(12)
+        s.p2p_selftest(3)
