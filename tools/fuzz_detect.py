@@ -1,0 +1,81 @@
+"""Robustness probe of the corner detector beyond the reference's axis-aligned synthetic boards: perspective
+views of a checkerboard (random pose, 3x3 supersampling, Gaussian blur, noise) rendered with numpy; the device
+detector must find the board and place every corner within 1 px of the projected truth (any of the 4 board
+symmetries counts as the same detection).  Prints failures and a summary."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cameracalibrations_amd import synthetic as syn  # noqa: E402
+from cameracalibrations_amd.detect import detect_corners  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=100)
+ap.add_argument("--seed", type=int, default=3)
+ap.add_argument("--max-tilt", type=float, default=0.5)
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+H, W = 480, 640            # rows, cols
+f = 600.0
+
+
+def render(n1, n2, rv, tv, blur_sigma, noise):
+    R = syn.rodrigues(rv[None])[0]
+    ss = 3
+    rr, cc = np.meshgrid((np.arange(H * ss) + 0.5) / ss - 0.5, (np.arange(W * ss) + 0.5) / ss - 0.5, indexing="ij")
+    # pixel (row, col) == (x_cv, y_cv) of the reference convention: x = row, y = col
+    d = np.stack([(rr - (H - 1) / 2) / f, (cc - (W - 1) / 2) / f, np.ones_like(rr)], axis=-1)
+    n = R[:, 2]
+    t = (tv @ n) / (d @ n)
+    Xc = d * t[..., None] - tv
+    b = Xc @ R                                   # board coordinates (squares), z ~ 0
+    u, v = b[..., 0], b[..., 1]
+    inside = (u > -1) & (u < n1) & (v > -1) & (v < n2) & (t > 0)
+    dark = ((np.floor(u).astype(int) + np.floor(v).astype(int)) % 2) == 0
+    img = np.where(inside, np.where(dark, 30.0, 225.0), 225.0)
+    # white margin of half a square around the board
+    img = img.reshape(H, ss, W, ss).mean(axis=(1, 3))
+    if blur_sigma > 0:
+        k = np.exp(-0.5 * (np.arange(-4, 5) / blur_sigma) ** 2)
+        k /= k.sum()
+        img = np.apply_along_axis(lambda m: np.convolve(m, k, mode="same"), 0, img)
+        img = np.apply_along_axis(lambda m: np.convolve(m, k, mode="same"), 1, img)
+    img = img + rng.normal(0, noise, img.shape)
+    obj = syn.board_template((n1, n2))
+    pc = obj @ R.T + tv
+    truth = np.stack([f * pc[:, 0] / pc[:, 2] + (H - 1) / 2, f * pc[:, 1] / pc[:, 2] + (W - 1) / 2], axis=1)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8), truth
+
+
+found, good, n_cases = 0, 0, 0
+for case in range(args.cases):
+    n1, n2 = int(rng.integers(4, 10)), int(rng.integers(4, 10))
+    if n1 == n2:
+        n2 += 1
+    rv = rng.uniform(-args.max_tilt, args.max_tilt, 3)
+    z = rng.uniform(1.6, 2.4) * max(n1, n2)
+    obj = syn.board_template((n1, n2))
+    R = syn.rodrigues(rv[None])[0]
+    tv = np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), z]) - R @ obj.mean(axis=0)
+    img, truth = render(n1, n2, rv, tv, float(rng.choice([0.0, 0.8, 1.5])), float(rng.choice([0.0, 3.0, 8.0])))
+    if truth.min() < 12 or truth[:, 0].max() > H - 13 or truth[:, 1].max() > W - 13:
+        continue
+    n_cases += 1
+    res = detect_corners(img, (n1, n2))
+    if res is None:
+        print(f"case {case}: {n1}x{n2} rv={np.round(rv, 2)} z={z:.1f}: NOT FOUND")
+        continue
+    found += 1
+    det = res.transpose(1, 0, 2).reshape(-1, 2)          # first dimension fastest, like the template
+    T = truth.reshape(n2, n1, 2)
+    cands = [T, T[::-1, ::-1], T[::-1], T[:, ::-1]]
+    err = min(np.linalg.norm(det - c.reshape(-1, 2), axis=1).max() for c in cands)
+    if err < 1.0:
+        good += 1
+    else:
+        print(f"case {case}: {n1}x{n2} rv={np.round(rv, 2)} z={z:.1f}: max corner error {err:.2f} px")
+print(f"{n_cases} boards rendered, {found} found, {good} with every corner within 1 px")
