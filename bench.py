@@ -66,6 +66,31 @@ def cpu_baseline(wl, criteria, budget_s=12.0):
                       f"oracle Schur mode, LM loop only; rms {r['rms']:.6f} px, iters {r['iters']}"}
 
 
+def opencv_baseline(wl, criteria, budget_s=20.0):
+    """if the box happens to have OpenCV's Python binding, time the real thing --
+    cv2.calibrateCamera with the reference's inputs (Float32 points, flag word, criteria) -- on a bounded
+    sample (its dense (18+6N)^2 solve is cubic in N).  Absent in this image; returns None then (or on any
+    error), and the port above stays the only baseline."""
+    try:
+        import cv2
+        import numpy as np
+        n = min(wl.n_images, 60)
+        obj = [wl.obj.astype(np.float32)] * n
+        img = [wl.img[i].astype(np.float32) for i in range(n)]
+        crit = (cv2.TERM_CRITERIA_COUNT + cv2.TERM_CRITERIA_EPS, int(criteria[0]), float(criteria[1]))
+        t0 = time.time()
+        reps, rms = 0, float("nan")
+        while time.time() - t0 < budget_s and reps < 20:
+            rms = cv2.calibrateCamera(obj, img, tuple(int(v) for v in wl.image_size), None, None, flags=int(wl.flags),
+                                      criteria=crit)[0]
+            reps += 1
+        dt = (time.time() - t0) / max(reps, 1)
+        return {"seconds_per_fit": dt, "images": n, "corners_per_image": wl.n_points, "rms_px": float(rms),
+                "what": "cv2.calibrateCamera incl. its own initialisation, single process", "version": cv2.__version__}
+    except Exception:      # noqa: BLE001
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,6 +290,9 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, CRITERIA)
+            ocv = opencv_baseline(wl, CRITERIA)
+            if ocv is not None:
+                out["cpu_baseline"]["opencv"] = ocv
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
