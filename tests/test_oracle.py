@@ -232,3 +232,27 @@ def test_golden_vectors(golden_dir):
             assert np.abs(r["tvecs"] - np.array(g["tvecs"])).max() < tol * 10, key
             if key.endswith("ref"):
                 assert (r["iters"], r["j_sweeps"], r["e_sweeps"]) == (g["iters"], g["j_sweeps"], g["e_sweeps"]), key
+
+
+def test_oracle_matches_opencv_when_available(golden_dir):
+    """Pins the oracle the day OpenCV is reachable: cv2.calibrateCamera on the reference's example corners with
+    the reference's flag word and criteria (src/detect_fit.jl:40,47, src/CameraCalibrations.jl:16) against the
+    restatement in its OpenCV-faithful dense mode.  Skipped in this image (no cv2): parity stays unpinned."""
+    cv2 = pytest.importorskip("cv2")
+    import json
+    ex = json.load(open(os.path.join(golden_dir, "example_corners.json")))
+    n_corners = tuple(ex["n_corners"])
+    img = np.array(ex["corners"], dtype=np.float64)
+    obj = syn.board_template(n_corners)
+    for flags in (orc.REF_FLAGS_DISTORTION, orc.REF_FLAGS_NO_DISTORTION):
+        K0 = np.eye(3)
+        rms, K, dist, rvecs, tvecs = cv2.calibrateCamera(
+            [obj.astype(np.float32)] * len(img), [m.astype(np.float32) for m in img], tuple(ex["image_size_wh"]), K0,
+            np.zeros(5), flags=int(flags), criteria=(cv2.TERM_CRITERIA_COUNT + cv2.TERM_CRITERIA_EPS, 30, 1e-3))
+        ro = orc.calibrate(obj, img, ex["image_size_wh"], flags=flags, solver="dense")
+        assert abs(rms - ro["rms"]) < 1e-6
+        assert abs(K[0, 0] - ro["intr"][0]) < 1e-4 * K[0, 0] and abs(K[1, 1] - ro["intr"][1]) < 1e-4 * K[1, 1]
+        assert abs(K[0, 2] - ro["intr"][2]) < 1e-2 and abs(K[1, 2] - ro["intr"][3]) < 1e-2
+        assert np.abs(np.ravel(dist)[:5] - ro["intr"][4:]).max() < 1e-4
+        assert np.abs(np.array(rvecs).reshape(-1, 3) - ro["rvecs"]).max() < 1e-4
+        assert np.abs(np.array(tvecs).reshape(-1, 3) - ro["tvecs"]).max() < 1e-3
