@@ -18,14 +18,16 @@
 //                     G = [Je|Ji|e]^T [Je|Ji|e]  (16x16; holds JtJ blocks, Jt e and ||e||^2)
 //                  4. damp + Cholesky of the 6x6 extrinsic block, Y = L^-1 [B^T | h], Schur
 //                     contribution Y^T Y, workgroup partial sums -> partials[block][68]
-//   k_lm_reduce  only when the partials are too many to be summed by every workgroup (large N)
-//                or have to leave the GPU first (multi-GPU): partial rows -> G rows (G = 1 is the
-//                all-reduced message).
+//   k_lm_reduce  only when the partials are too many to be summed by every workgroup (large N) or a
+//                collective library sums them across GPUs (RCCL / host hook): partial rows -> G rows.
+//   k_lm_exchange  multi-GPU with many workgroups: partial rows -> one row -> direct xGMI exchange.
 //
 // A solve of T trials is T + 1 launches of k_lm_trial (the last one runs the prologue only).
 // A rejected step costs one extra sweep of the accepted point with the larger lambda.
-// Multi-GPU: k_lm_reduce -> all-reduce of the 68-double row (host hook / RCCL) -> next k_lm_trial;
-// every rank then advances the same state.
+// Multi-GPU (images sharded): every rank sums its own rows, the 68-double row is summed over the ranks
+// and every rank advances the same state.  Default transport: the direct row exchange fused into the
+// prologue (k_lm_trial<true>, ccal_p2p.hpp) -- no extra launch; alternatives: k_lm_reduce -> RCCL or
+// a host hook -> next k_lm_trial.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
