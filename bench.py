@@ -112,6 +112,9 @@ def main():
     ap.add_argument("--allreduce", default=os.environ.get("CCAL_ALLREDUCE", "p2p"), choices=["p2p", "rccl", "torch"],
                     help="N > 1: 'p2p' = direct xGMI row exchange kernels (self-tested at start-up, else falls back), "
                          "'rccl' = ncclAllReduce called by the library itself, 'torch' = torch.distributed hook")
+    ap.add_argument("--strong", action="store_true",
+                    help="N > 1: shard ONE problem of the named size over the ranks (BASELINE.json configs[3]) instead of "
+                         "giving every rank its own shard of that size; the JSON then says scaling = strong")
     ap.add_argument("--timed-only", action="store_true",
                     help="profiling runs: only the timed solves (skip the converged-criteria run, so that counter means "
                          "are means over the timed region's launches)")
@@ -145,9 +148,17 @@ def main():
     cdev = "cpu" if (world > 1 and args.share_gpu) else dev          # where torch.distributed tensors live
 
     # per-rank shard of the joint problem (different images on every rank, same camera)
-    wl = syn.named_workload(args.workload, n_images=args.images, seed_offset=1000 * rank)
-    N, P = wl.n_images, wl.n_points
-    img_dev = torch.from_numpy(wl.img).to(dev)                      # inputs resident in HBM
+    strong = bool(args.strong and world > 1)
+    if strong:
+        from cameracalibrations_amd.distributed import shard_range
+        wl = syn.named_workload(args.workload, n_images=args.images)
+        lo, hi = shard_range(wl.n_images, world, rank)
+        n_total, my_img = wl.n_images, wl.img[lo:hi]
+    else:
+        wl = syn.named_workload(args.workload, n_images=args.images, seed_offset=1000 * rank)
+        n_total, my_img = wl.n_images * world, wl.img
+    N, P = my_img.shape[0], wl.n_points
+    img_dev = torch.from_numpy(np.ascontiguousarray(my_img)).to(dev)   # inputs resident in HBM
     torch.cuda.synchronize()
     # the context's own non-blocking stream (not torch's legacy default stream, which serialises with every
     # blocking stream of the process): the timed region is bracketed by device-wide synchronisation anyway
@@ -167,7 +178,7 @@ def main():
         if args.allreduce == "p2p":
             why = ""
             try:
-                sol.init_p2p(world, rank, N * world, allgather_bytes_via_torch())
+                sol.init_p2p(world, rank, n_total, allgather_bytes_via_torch())
                 ok = True
             except Exception as exc:      # noqa: BLE001
                 ok, why = False, str(exc)
@@ -187,11 +198,11 @@ def main():
             print(f"[bench] rank {rank}: direct exchange unavailable ({why or 'a peer failed'}); using RCCL", file=sys.stderr)
         if args.allreduce in ("p2p", "rccl"):
             try:
-                sol.init_rccl(world, rank, N * world, broadcast_id_via_torch())
+                sol.init_rccl(world, rank, n_total, broadcast_id_via_torch())
                 return "rccl (ncclAllReduce inside the library)"
             except Exception as exc:      # noqa: BLE001 - fall back to the torch hook on every rank
                 print(f"[bench] rank {rank}: native RCCL unavailable ({exc}); using the torch hook", file=sys.stderr)
-        sol.set_allreduce(TorchAllReduce(), world, rank, N * world)
+        sol.set_allreduce(TorchAllReduce(), world, rank, n_total)
         return "torch.distributed all_reduce hook"
 
     comm_kind = attach_comm(s)
@@ -260,7 +271,7 @@ def main():
         rt = s.result()
 
     if rank == 0:
-        units = float(N) * world * P * sweeps
+        units = float(n_total) * P * sweeps
         alg_bytes = algorithmic_bytes_per_sweep(N, P)
         achieved = alg_bytes / (sweep_us * 1e-6) / 1e9 if sweep_us > 0 else 0.0
         out = {
@@ -272,7 +283,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic" if not args.share_gpu else "synthetic (REHEARSAL: all ranks share one GPU, not a measurement)",
