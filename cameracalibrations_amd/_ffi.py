@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libccal_hip.so")
+LIB_PATH = os.environ.get("CCAL_LIB") or os.path.join(_HERE, "libccal_hip.so")   # CCAL_LIB: variant builds (tools/)
 NINTR = 9
 
 # status codes (include/ccal.h)

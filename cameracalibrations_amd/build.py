@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SOURCES = ["ccal_lm.hip", "ccal_init.hip", "ccal_maps.hip", "ccal_comm.hip", "ccal_p2p.hip", "ccal_detect.hip", "ccal_api.hip"]
-HEADERS = ["ccal_math.hpp", "ccal_state.hpp", "ccal_wave.hpp", "ccal_kernels.hpp", "ccal_comm.hpp", "ccal_p2p.hpp", "ccal_p2p_dev.hpp", "ccal_detect.hpp",
+HEADERS = ["ccal_acc.hpp", "ccal_math.hpp", "ccal_state.hpp", "ccal_wave.hpp", "ccal_kernels.hpp", "ccal_comm.hpp", "ccal_p2p.hpp", "ccal_p2p_dev.hpp", "ccal_detect.hpp",
            "../../include/ccal.h"]
 LIB = os.path.join(HERE, "libccal_hip.so")
 # max-ilp: the hot kernels run one wave per SIMD, so the scheduler should hide FP64 latency inside the wave

@@ -1,0 +1,80 @@
+// ccal_acc.hpp -- exact, order-independent accumulation of doubles in fixed-point limbs
+// (layout and range: ccal_state.hpp).  Plain integer code, __host__ __device__ so that
+// tests/test_acc_host.py can build a host shim of the SAME functions and check them against
+// arbitrary-precision arithmetic on the CPU; the product only runs them on the device.
+#pragma once
+
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+
+#include "ccal_state.hpp"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define CCAL_ACC_HD __host__ __device__ __forceinline__
+#else
+#define CCAL_ACC_HD inline
+#endif
+
+namespace ccal {
+
+CCAL_ACC_HD int64_t acc_bits(double x) {
+    int64_t b;
+    memcpy(&b, &x, 8);
+    return b;
+}
+
+// x -> limb index j and the two signed addends for limbs j and j + 1 (x == lo * 2^(52 j - 150) +
+// hi * 2^(52 (j + 1) - 150) exactly, up to bits below 2^-150 which are dropped towards zero).
+// flag: 0 ok, 1 NaN, 2 infinite or |x| >= 2^109 (then lo = hi = 0).
+CCAL_ACC_HD void acc_split(double x, int &j, int64_t &lo, int64_t &hi, int &flag) {
+    const int64_t bits = acc_bits(x);
+    const int ex = (int)((bits >> 52) & 0x7ff);
+    const int64_t frac = bits & 0xfffffffffffffll;
+    j = 0; lo = 0; hi = 0; flag = 0;
+    if (ex == 0x7ff) { flag = frac ? 1 : 2; return; }
+    if (ex == 0) return;                                       // zero / subnormal: far below the resolution
+    int64_t m = frac | (1ll << 52);                            // |x| = m * 2^(ex - 1075)
+    int s = ex - 1075 - ACC_LSB_EXP;                           // position of m's lowest bit in the fixed-point number
+    if (s + 53 > ACC_LIMBS * ACC_LIMB_BITS - 1) { flag = 2; return; }
+    if (s < 0) {
+        if (s <= -53) return;
+        m >>= -s;
+        s = 0;
+    }
+    j = s / ACC_LIMB_BITS;
+    const int o = s - ACC_LIMB_BITS * j;
+    lo = (int64_t)(((uint64_t)m << o) & ((1ull << ACC_LIMB_BITS) - 1));
+    hi = m >> (ACC_LIMB_BITS - o);
+    if (bits < 0) { lo = -lo; hi = -hi; }
+}
+
+// Sum over replicas of one limb, kept as two partial sums in binary64: a == (a >> 32) * 2^32 + (a & 0xffffffff)
+// for two's-complement a, both halves convert exactly (one v_cvt each on the device) and their sums over at
+// most 64 replicas stay far below 2^53, so the partial sums are exact integers -- without 64-bit integer
+// arithmetic, which gfx950 would have to emulate with two 32-bit instructions per operation.
+struct AccPart { double hi, lo; };
+CCAL_ACC_HD void acc_part_add(AccPart &p, int64_t a) {
+    p.hi += (double)(int32_t)(a >> 32);
+    p.lo += (double)(uint32_t)((uint64_t)a & 0xffffffffull);
+}
+
+// limbs (as AccPart sums) -> double: value = sum_j (hi_j 2^32 + lo_j) 2^(52 j - 150), added from the top limb
+// down.  Every term is an exact double.  A partial sum is only rounded when it is not about to be cancelled:
+// the terms below limb j are together smaller than 2^12 units of limb j, so either the running sum is that
+// small and everything is still exact, or it dominates and the rounding is relative to the result.  The
+// result is within a few ulp of the exact total and a pure function of it (same bits in every workgroup).
+CCAL_ACC_HD double acc_decode(const AccPart part[ACC_LIMBS]) {
+    // 2^(52 j - 150) and 2^32 times that
+    const double w[ACC_LIMBS] = {0x1p-150, 0x1p-98, 0x1p-46, 0x1p6, 0x1p58};
+    const double w32[ACC_LIMBS] = {0x1p-118, 0x1p-66, 0x1p-14, 0x1p38, 0x1p90};
+    double v = 0.0;
+    for (int j = ACC_LIMBS - 1; j >= 0; j--) {
+        v = fma(part[j].hi, w32[j], v);
+        v = fma(part[j].lo, w[j], v);
+    }
+    return v;
+}
+
+}  // namespace ccal

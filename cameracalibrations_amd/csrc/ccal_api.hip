@@ -27,11 +27,12 @@ using namespace ccal;
 namespace ccal { hipError_t debug_read_stamps(unsigned long long *out); hipError_t debug_read_init_stamps(unsigned long long *out); hipError_t debug_read_init_blocks(unsigned int *out); }
 #endif
 
-// prologue reduction: every workgroup sums the previous partials itself while they are few; beyond
-// DIRECT_MAX_BLOCKS (or when the sum has to leave the GPU) k_lm_reduce condenses them first
-static constexpr int DIRECT_MAX_BLOCKS = 320;
-static constexpr int REDUCE_ROWS = 64;
-static constexpr int SHARD_ROWS = 16;
+// direct xGMI exchange: fused into the prologue of k_lm_trial while a rank has at most this many
+// workgroups (every one of them polls the inbox); beyond it one k_lm_exchange workgroup per trial does it.
+// Decided from the GLOBAL problem size so that every rank of a fit takes the same path.
+static constexpr int FUSED_XCHG_MAX_BLOCKS = 320;
+
+static constexpr size_t ACC_BYTES = sizeof(long long) * ACC_BUFS * ACC_MAX_REPLICAS * ACC_ROW;
 
 static thread_local std::string g_err;
 
@@ -64,7 +65,10 @@ struct ccal_ctx {
     const float *d_img = nullptr;
     size_t img_cap = 0, n_cap = 0;
     int p_cap = 0;
-    double *d_ext0 = nullptr, *d_blk = nullptr, *d_partials = nullptr, *d_red = nullptr;
+    double *d_ext0 = nullptr, *d_blk = nullptr, *d_red = nullptr;
+    long long *d_acc = nullptr, *d_acc_scratch = nullptr;   // [3][R][ACC_ROW] exact accumulators (+ one set for diagnostics launches)
+    int acc_R = 8;
+    bool acc_dirty = true;             // the accumulators are not known to be all zero (cleared before the next solve)
     double *d_H = nullptr, *d_foc_partials = nullptr, *d_foc_red = nullptr, *d_gram = nullptr;
     int *d_fail = nullptr;
     double *d_intr0 = nullptr, *d_intr_scratch = nullptr;   // initial intrinsics [9] on the device
@@ -94,8 +98,8 @@ struct ccal_ctx {
     // one solve = one replayable graph: begin + lm_batch x (sweep, solve) + state read-back
     hipGraphExec_t g_first = nullptr;
     struct GraphKey {             // everything baked into the captured launches
-        const void *obj, *img, *blk, *st, *partials, *red, *trace, *intr0, *ext0;
-        int N, P, batch;
+        const void *obj, *img, *blk, *st, *acc, *red, *trace, *intr0, *ext0;
+        int N, P, batch, R;
         LmInit init;
     } graph_key{};
     bool defer_sync = false;      // one-shot path: stage syncs and checks are batched at the end
@@ -109,9 +113,9 @@ struct ccal_ctx {
 };
 
 static void free_problem_buffers(ccal_ctx *c) {
-    (void)hipFree(c->d_obj); (void)hipFree(c->d_img_own); (void)hipFree(c->d_ext0); (void)hipFree(c->d_blk); (void)hipFree(c->d_partials);
+    (void)hipFree(c->d_obj); (void)hipFree(c->d_img_own); (void)hipFree(c->d_ext0); (void)hipFree(c->d_blk);
     (void)hipFree(c->d_H); (void)hipFree(c->d_foc_partials); (void)hipFree(c->d_gram);
-    c->d_obj = nullptr; c->d_img_own = nullptr; c->d_ext0 = c->d_blk = c->d_partials = nullptr;
+    c->d_obj = nullptr; c->d_img_own = nullptr; c->d_ext0 = c->d_blk = nullptr;
     c->d_H = c->d_foc_partials = c->d_gram = nullptr;
     c->img_cap = 0; c->n_cap = 0; c->p_cap = 0;
 }
@@ -161,7 +165,9 @@ int ccal_create(int device, ccal_ctx **out) {
     c->stream = c->own_stream;
     HIPCHK(hipMalloc(&c->d_st, sizeof(LmState) * 2));          // S_k lives in d_st[k & 1]
     HIPCHK(hipMalloc(&c->d_st_scratch, sizeof(LmState) * 2));
-    HIPCHK(hipMalloc(&c->d_red, sizeof(double) * NRED * REDUCE_ROWS));
+    HIPCHK(hipMalloc(&c->d_red, sizeof(double) * NRED));
+    HIPCHK(hipMalloc(&c->d_acc, ACC_BYTES));
+    HIPCHK(hipMalloc(&c->d_acc_scratch, ACC_BYTES));
     HIPCHK(hipMalloc(&c->d_foc_red, sizeof(double) * NFOC));
     HIPCHK(hipMalloc(&c->d_fail, sizeof(int) * 4));
     HIPCHK(hipMalloc(&c->d_intr0, sizeof(double) * 9));
@@ -185,6 +191,7 @@ void ccal_destroy(ccal_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     free_problem_buffers(c);
     (void)hipFree(c->d_st); (void)hipFree(c->d_st_scratch); (void)hipFree(c->d_red); (void)hipFree(c->d_foc_red); (void)hipFree(c->d_fail);
+    (void)hipFree(c->d_acc); (void)hipFree(c->d_acc_scratch);
     (void)hipFree(c->d_trace); (void)hipFree(c->d_intr0); (void)hipFree(c->d_intr_scratch);
     if (c->g_first) (void)hipGraphExecDestroy(c->g_first);
     (void)hipHostFree(c->h_st); (void)hipHostFree(c->h_flags);
@@ -345,7 +352,6 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
         HIPCHK(hipMalloc(&c->d_obj, sizeof(float) * 3 * P));
         HIPCHK(hipMalloc(&c->d_ext0, sizeof(double) * n * EXT));
         HIPCHK(hipMalloc(&c->d_blk, sizeof(double) * 2 * n * BLK));
-        HIPCHK(hipMalloc(&c->d_partials, sizeof(double) * 2 * (size_t)lm_sweep_blocks(N) * NRED));
         HIPCHK(hipMalloc(&c->d_H, sizeof(double) * n * 9));
         HIPCHK(hipMalloc(&c->d_foc_partials, sizeof(double) * n * NFOC));
         c->n_cap = n;
@@ -357,6 +363,12 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
     if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));   // `obj` may be released by the caller after return
     c->P = P; c->N = N; c->width = width; c->height = height; c->aspect = aspect; c->flags = flags;
     c->max_iter = max_iter; c->eps = eps;
+    c->acc_R = lm_acc_replicas(lm_sweep_blocks(N));
+    if (const char *r = getenv("CCAL_ACC_REPLICAS")) {      // experiments: 1, 2, 4, ... 64
+        const int v = atoi(r);
+        if (v >= 1 && v <= ACC_MAX_REPLICAS && (v & (v - 1)) == 0 && (lm_sweep_blocks(N) + v - 1) / v <= 2000) c->acc_R = v;
+    }
+    c->acc_dirty = true;               // the buffer layout depends on the replica count
     c->have_problem = true;
     c->have_img = c->have_intr = c->have_ext = c->have_result = false;
     c->d_img = nullptr;
@@ -563,53 +575,44 @@ static int wait_progress(ccal_ctx *c, long target_trials) {
 
 static TrialLaunch base_launch(ccal_ctx *c) {
     TrialLaunch t;
-    t.obj = c->d_obj; t.img = c->d_img; t.blk = c->d_blk; t.st = c->d_st; t.partials = c->d_partials;
+    t.obj = c->d_obj; t.img = c->d_img; t.blk = c->d_blk; t.st = c->d_st; t.acc = c->d_acc; t.R = c->acc_R;
     t.trace = c->d_trace; t.host_result = c->h_st; t.host_progress = progress_word(c);
     t.intr0 = c->d_intr0; t.ext0 = c->d_ext0; t.ext0_stride = EXT; t.init = make_init(c);
     t.N = c->N; t.P = c->P;
     return t;
 }
 
-// Launch trial k (k_lm_trial): its prologue consumes the partials of trial k - 1 -- directly, or
-// condensed by k_lm_reduce (many workgroups), or all-reduced across GPUs (sharded fits).
+// the exchange is fused into the trial's prologue unless the ranks of this fit run many workgroups each
+static bool xchg_fused(const ccal_ctx *c) {
+    const int64_t ng = c->n_global > 0 ? c->n_global : c->N;
+    const int64_t per_rank = (ng + c->world - 1) / (c->world > 0 ? c->world : 1);
+    return lm_sweep_blocks((int)per_rank) <= FUSED_XCHG_MAX_BLOCKS;
+}
+
+// Launch trial k (k_lm_trial): its prologue consumes the exact accumulators of trial k - 1 -- directly
+// (single GPU, or the fused xGMI exchange), or as one row of doubles that was summed across GPUs
+// between the two launches (k_lm_row -> RCCL / host hook, or k_lm_exchange).
 static int enqueue_trial(ccal_ctx *c, hipStream_t stream, int k, bool final_only) {
     TrialLaunch t = base_launch(c);
     t.k = k;
     t.first = k == 0;
     t.final_only = final_only ? 1 : 0;
-    const int nb = lm_sweep_blocks(c->N);
     if (via_p2p(c)) t.p2p = &c->p2p->dev();
     if (k > 0) {
-        const double *prev = c->d_partials + (size_t)((k - 1) & 1) * nb * NRED;
         if (via_p2p(c)) {
-            if (nb > DIRECT_MAX_BLOCKS) {
-                // one launch: condense the partials, exchange the row with the peers over xGMI, sum in rank order
-                HIPCHK(launch_lm_exchange(stream, prev, nb, c->d_red, c->p2p->dev(), k));
-                t.rows_in = c->d_red;
-                t.n_in = 1;
+            if (xchg_fused(c)) {
+                t.xchg_fused = 1;      // the prologue decodes the local row and exchanges it itself
             } else {
-                // the prologue of the trial sums the local rows and exchanges the result itself
-                t.rows_in = prev;
-                t.n_in = nb;
-                t.xchg_fused = 1;
+                // one launch: local row, exchange with the peers over xGMI, sum in rank order
+                HIPCHK(launch_lm_exchange(stream, c->d_acc, c->acc_R, c->d_st, c->d_red, c->p2p->dev(), k));
+                t.row_in = c->d_red;
             }
         } else if (sharded(c)) {
-            // 16 workgroups condense the partials (one would be bound by a single CU's ~64 GB/s); the
-            // 16 rows (8.7 KB, still latency-bound) are summed across GPUs and added up in the prologue
-            // (always 16: the message size must not depend on the local shard size; surplus rows are zero)
-            const int rows = SHARD_ROWS;
-            HIPCHK(launch_lm_reduce(stream, prev, nb, c->d_red, rows));
-            const int rc = run_allreduce(c, c->d_red, NRED * rows);
+            // local row (one workgroup) -> 68 doubles summed across GPUs on the launch stream
+            HIPCHK(launch_lm_row(stream, c->d_acc, c->acc_R, c->d_st, k, c->d_red));
+            const int rc = run_allreduce(c, c->d_red, NRED);
             if (rc) return rc;
-            t.rows_in = c->d_red;
-            t.n_in = rows;
-        } else if (nb > DIRECT_MAX_BLOCKS) {
-            HIPCHK(launch_lm_reduce(stream, prev, nb, c->d_red, REDUCE_ROWS));
-            t.rows_in = c->d_red;
-            t.n_in = REDUCE_ROWS;
-        } else {
-            t.rows_in = prev;
-            t.n_in = nb;
+            t.row_in = c->d_red;
         }
     }
     if (!final_only && c->time_sweeps && c->ev_used < MAX_KINDS) {
@@ -658,11 +661,17 @@ static int lm_begin(ccal_ctx *c) {
     c->ev_used = 0;
     c->h_st->done = 0;
     *progress_word(c) = 0ull;
+    if (c->acc_dirty) {
+        // first solve of a problem, or the last one did not end with its terminating launch (which leaves
+        // the accumulators cleared): start from zeros
+        HIPCHK(hipMemsetAsync(c->d_acc, 0, ACC_BYTES, c->stream));
+    }
+    c->acc_dirty = true;               // until this solve is seen to have ended with its terminating launch
     c->run_graphed = c->use_graph && !c->time_sweeps && (!sharded(c) || via_p2p(c));
     if (c->run_graphed) {
         ccal_ctx::GraphKey key;
         memset(&key, 0, sizeof key);
-        key.obj = c->d_obj; key.img = c->d_img; key.blk = c->d_blk; key.st = c->d_st; key.partials = c->d_partials;
+        key.obj = c->d_obj; key.img = c->d_img; key.blk = c->d_blk; key.st = c->d_st; key.acc = c->d_acc; key.R = c->acc_R;
         key.red = c->d_red; key.trace = c->d_trace; key.intr0 = c->d_intr0; key.ext0 = c->d_ext0;
         key.N = c->N; key.P = c->P; key.batch = c->lm_batch; key.init = make_init(c);
         if (c->graph_dirty || !c->g_first || memcmp(&key, &c->graph_key, sizeof key) != 0) {
@@ -712,6 +721,7 @@ static int lm_end(ccal_ctx *c) {
         if (c->p2p->check_and_clear(err)) return fail(CCAL_E_COMM, "ccal_lm_run: " + err);
     }
     const LmState &r = *c->h_st;
+    if (r.done) c->acc_dirty = false;  // the terminating launch cleared every accumulator buffer
     c->stats.t_lm_s = now_s() - t0;
     c->dbg_total_s += c->stats.t_lm_s;
     if (++c->dbg_runs == 200 && getenv("CCAL_DEBUG_TIMING"))
@@ -779,9 +789,9 @@ int ccal_get_result(ccal_ctx *c, double intr[CCAL_NINTR], double *rvecs, double 
     const LmState &r = *c->h_st;
     if (intr) memcpy(intr, r.intr_prev, sizeof(double) * 9);
     if (rvecs || tvecs) {
-        // rvec,tvec are the first 6 doubles of each image's block of the accepted parity
+        // rvec,tvec sit at words BLK_EXT.. of each image's block of the accepted parity
         std::vector<double> e((size_t)c->N * 8);
-        HIPCHK(hipMemcpy2DAsync(e.data(), sizeof(double) * 8, c->d_blk + (size_t)r.parity * c->N * BLK,
+        HIPCHK(hipMemcpy2DAsync(e.data(), sizeof(double) * 8, c->d_blk + (size_t)r.parity * c->N * BLK + BLK_EXT,
                                 sizeof(double) * BLK, sizeof(double) * 8, (size_t)c->N, hipMemcpyDeviceToHost,
                                 c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -1165,6 +1175,7 @@ int ccal_debug_image_grams(ccal_ctx *c, const double intr[CCAL_NINTR], const dou
     HIPCHK(hipMemcpyAsync(c->d_intr_scratch, intr, sizeof(double) * 9, hipMemcpyHostToDevice, c->stream));
     TrialLaunch t = base_launch(c);
     t.st = c->d_st_scratch; t.trace = nullptr; t.host_result = nullptr; t.host_progress = nullptr;
+    t.acc = c->d_acc_scratch;          // diagnostics launches never touch the accumulators of a solve
     t.intr0 = c->d_intr_scratch; t.gram_out = c->d_gram; t.first = 1; t.k = 0;
     HIPCHK(launch_lm_trial(c->stream, t));
     HIPCHK(hipMemcpyAsync(G_host, c->d_gram, sizeof(double) * (size_t)c->N * 256, hipMemcpyDeviceToHost, c->stream));
@@ -1182,11 +1193,12 @@ int ccal_time_sweep(ccal_ctx *c, int32_t reps, double *avg_us) {
     // initial values; back-to-back launches, so the mean includes one kernel boundary
     TrialLaunch t = base_launch(c);
     t.st = c->d_st_scratch; t.trace = nullptr; t.host_result = nullptr; t.host_progress = nullptr;
+    t.acc = c->d_acc_scratch;
     t.first = 1; t.k = 0;
     if (c->have_result) {
         const LmState *fin = c->d_st + (c->h_st->trials & 1);
         t.intr0 = reinterpret_cast<const double *>(reinterpret_cast<const char *>(fin) + offsetof(LmState, intr_prev));
-        t.ext0 = c->d_blk + (size_t)c->h_st->parity * c->N * BLK;
+        t.ext0 = c->d_blk + (size_t)c->h_st->parity * c->N * BLK + BLK_EXT;
         t.ext0_stride = BLK;
     }
     hipEvent_t e0, e1;

@@ -14,9 +14,9 @@ struct TrialLaunch {              // one launch of k_lm_trial (see ccal_lm.hip)
     const float *obj = nullptr, *img = nullptr;
     double *blk = nullptr;
     LmState *st = nullptr;        // [2]
-    double *partials = nullptr;   // [2][nblocks][NRED]
-    const double *rows_in = nullptr;
-    int n_in = 0;
+    long long *acc = nullptr;     // [3][R][ACC_ROW] exact accumulators of the reduced system (ccal_acc.hpp)
+    int R = 8;                    // replicas per buffer (lm_acc_replicas)
+    const double *row_in = nullptr;   // != NULL: the prologue reads this all-reduced row instead of the accumulators
     TraceRec *trace = nullptr;
     LmState *host_result = nullptr;
     unsigned long long *host_progress = nullptr;
@@ -30,10 +30,13 @@ struct TrialLaunch {              // one launch of k_lm_trial (see ccal_lm.hip)
     int xchg_fused = 0;           // ... whose prologue runs the row exchange itself
 };
 hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t);
-hipError_t launch_lm_reduce(hipStream_t stream, const double *rows, int n_rows, double *out, int G);
-// multi-GPU, many partial rows: partial rows -> one row -> sum over the node's ranks by direct xGMI
-// exchange -> out[0..68), as exchange k of the current solve (few rows: fused into k_lm_trial)
-hipError_t launch_lm_exchange(hipStream_t stream, const double *rows, int n_rows, double *out, const P2PDev &p, int k);
+int lm_acc_replicas(int nblocks);
+// accumulators of trial k - 1 -> out[0..68) (what RCCL / a host hook then sums across GPUs); no-op after `done`
+hipError_t launch_lm_row(hipStream_t stream, const long long *acc, int R, const LmState *st, int k, double *out);
+// multi-GPU, many workgroups per rank: accumulators -> one row -> sum over the node's ranks by direct xGMI
+// exchange -> out[0..68), as exchange k of the current solve (few workgroups: fused into k_lm_trial)
+hipError_t launch_lm_exchange(hipStream_t stream, const long long *acc, int R, const LmState *st, double *out, const P2PDev &p,
+                              int k);
 
 // ccal_init.hip -- closed-form initialisation
 constexpr int NFOC = 8;   // doubles all-reduced for the focal least squares: AtA(3) Atb(2) fail(1) pad(2)

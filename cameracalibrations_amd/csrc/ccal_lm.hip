@@ -5,10 +5,12 @@
 //
 // ONE kernel per LM trial, decisions made on the device (the host only reads `done`):
 //
-//   k_lm_trial   prologue, every workgroup redundantly: fixed-order sum of the previous trial's
-//                workgroup partials (deterministic: identical bits in every workgroup), then one lane
+//   k_lm_trial   prologue, every workgroup redundantly: the reduced intrinsic system of the previous
+//                trial is read from the exact accumulators (R replicas x 5 limbs x 68 columns of int64,
+//                22 KB at R = 8 -- not one row per workgroup), turned back into 68 doubles, and wave 0
 //                advances the CvLevMarq state machine on an LDS copy of the state: accept / reject,
-//                lambda schedule, stop rule, and the 9x9 damped Schur system for this trial's step.
+//                lambda schedule, stop rule, and the 9x9 damped Schur system for this trial's step,
+//                factored with one matrix row per lane (v_readlane broadcasts of the pivot column).
 //                Workgroup 0 persists the state (double-buffered by trial parity) and reports to the
 //                host.  Then the sweep: one 64-lane wavefront per image, one lane per corner.
 //                  1. back-substitute this image's extrinsic step from the factor stored by the
@@ -17,22 +19,26 @@
 //                  3. rows -> LDS (padded, conflict-free) -> v_mfma_f64_16x16x4_f64:
 //                     G = [Je|Ji|e]^T [Je|Ji|e]  (16x16; holds JtJ blocks, Jt e and ||e||^2)
 //                  4. damp + Cholesky of the 6x6 extrinsic block, Y = L^-1 [B^T | h], Schur
-//                     contribution Y^T Y, workgroup partial sums -> partials[block][68]
-//   k_lm_reduce  only when the partials are too many to be summed by every workgroup (large N) or a
-//                collective library sums them across GPUs (RCCL / host hook): partial rows -> G rows.
-//   k_lm_exchange  multi-GPU with many workgroups: partial rows -> one row -> direct xGMI exchange.
+//                     contribution Y^T Y, workgroup sums -> fixed-point limbs -> integer atomics
+//                     into acc[k % 3][blockIdx % R] (ccal_acc.hpp: exact, order-independent)
+//   k_lm_row     only when a collective library sums the system across GPUs (RCCL / host hook):
+//                accumulators -> one row of 68 doubles.
+//   k_lm_exchange  multi-GPU with many workgroups: accumulators -> one row -> direct xGMI exchange.
 //
-// A solve of T trials is T + 1 launches of k_lm_trial (the last one runs the prologue only).
+// A solve of T trials is T + 1 launches of k_lm_trial (the last one runs the prologue only and
+// leaves the accumulators cleared for the next solve).
 // A rejected step costs one extra sweep of the accepted point with the larger lambda.
-// Multi-GPU (images sharded): every rank sums its own rows, the 68-double row is summed over the ranks
+// Multi-GPU (images sharded): every rank forms its own row, the 68-double row is summed over the ranks
 // and every rank advances the same state.  Default transport: the direct row exchange fused into the
-// prologue (k_lm_trial<true>, ccal_p2p.hpp) -- no extra launch; alternatives: k_lm_reduce -> RCCL or
+// prologue (k_lm_trial<true>, ccal_p2p.hpp) -- no extra launch; alternatives: k_lm_row -> RCCL or
 // a host hook -> next k_lm_trial.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
 #include <cstring>
+#include <type_traits>
 
+#include "ccal_acc.hpp"
 #include "ccal_kernels.hpp"
 #include "ccal_math.hpp"
 #include "ccal_p2p_dev.hpp"
@@ -48,10 +54,13 @@ constexpr int WAVES = 4;             // images per workgroup
 // Diagnostic build only (-DCCAL_STAMPS): s_memtime stamps of one wave at the phase boundaries
 // of the sweep, read back through ccal_debug_stamps().  No stamp executes in the product build.
 #ifdef CCAL_STAMPS
+#ifndef CCAL_STAMP_BLOCK
+#define CCAL_STAMP_BLOCK 7
+#endif
 __device__ unsigned long long g_stamps[32];
 #define STAMP(i)                                                                              \
     do {                                                                                      \
-        if (blockIdx.x == 7 && tid == 0) {                                                    \
+        if (blockIdx.x == CCAL_STAMP_BLOCK && tid == 0) {                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                \
             unsigned long long t_;                                                            \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
@@ -59,9 +68,17 @@ __device__ unsigned long long g_stamps[32];
             __builtin_amdgcn_sched_barrier(0);                                                \
         }                                                                                     \
     } while (0)
+#define STAMP_RT(i)                                                                           \
+    do {                                                                                      \
+        if (blockIdx.x == CCAL_STAMP_BLOCK && tid == 0) {                                                    \
+            unsigned long long t_;                                                            \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+            g_stamps[i] = t_;                                                                 \
+        }                                                                                     \
+    } while (0)
 #define STAMP2(i)                                                                             \
     do {                                                                                      \
-        if (blockIdx.x == 7 && threadIdx.x == 0) {                                                               \
+        if (blockIdx.x == CCAL_STAMP_BLOCK && threadIdx.x == 0) {                                                               \
             __builtin_amdgcn_sched_barrier(0);                                                \
             unsigned long long t_;                                                            \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
@@ -72,6 +89,7 @@ __device__ unsigned long long g_stamps[32];
 #else
 #define STAMP(i) do { } while (0)
 #define STAMP2(i) do { } while (0)
+#define STAMP_RT(i) do { } while (0)
 #endif
 
 // packed-lower decode o -> (a, b), a >= b, for o < 55 (no memory table: arithmetic in the
@@ -97,210 +115,297 @@ __device__ void lm_trace(LmState *st, TraceRec *trace, double err, double rel, i
 
 __device__ __forceinline__ double pow10_lg(const LmState *st, int lg) { return st->pow10[lg + 16]; }
 
+// wave-uniform copy of lane `src`'s value (src is a compile-time constant after unrolling)
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
+                            __builtin_amdgcn_readlane(__double2loint(v), src));
+}
+
+constexpr int SROW = 10;       // row stride (doubles) of the symmetric copy of S0 in LDS: rows start 16-byte aligned
+
+// 10^lg out of the four pre-read table entries (values, not references: stays in registers)
+__device__ __forceinline__ double lam_pick(int lg, int lg0, int lg_dn, double same, double up, double dn, double dn2) {
+    double v = dn2;
+    v = (lg == lg_dn) ? dn : v;
+    v = (lg == lg0 + 1) ? up : v;
+    v = (lg == lg0) ? same : v;
+    return v;
+}
+
+// 1 / d for a normal positive d: v_rcp_f64 + two Newton steps (no division sequence, no special cases)
+__device__ __forceinline__ double rcp_pos(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-d, y, 1.0);
+    return fma(y, e, y);
+}
+
+// The nine elimination steps of the 9x9 solve, rows in lanes 0..8 (lanes 9..15 mirror row 8): pivot and
+// pivot row reach the other lanes of the 16-lane row through DPP row broadcasts of lane J.
+template <int J>
+__device__ __forceinline__ void gj9_steps(double (&a)[9], double &b, double &diag, bool &ok, int lane, std::integral_constant<int, J>) {
+    const double d = row_bcast16<J>(a[J]);          // pivot
+    ok = ok && (d > 0.0) && (d < 1.0e300);
+    double prow[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) prow[k] = k > J ? row_bcast16<J>(a[k]) : 0.0;
+    const double pb = row_bcast16<J>(b);
+    gj_row_step<9>(J, lane == J, d, __builtin_amdgcn_rcp(d), prow, pb, a, b, diag);
+    if constexpr (J < 8) gj9_steps(a, b, diag, ok, lane, std::integral_constant<int, J + 1>());
+}
+
 // [OCV-K CvLevMarq::updateAlt], SURVEY.md A.6, fused with the next step().
-// Every workgroup runs this on its own LDS copy of the state and reaches the same decisions;
+// Run by wave 0 of every workgroup on the workgroup's LDS copy of the state (every workgroup reaches
+// the same decisions from the same bits); all 64 lanes execute it.  A trial's kernel time is one
+// wavefront's dependent instruction chain, so the function is laid out for a short chain:
+//   * everything it needs is read from LDS in one burst,
+//   * the step of the next trial is solved SPECULATIVELY, in the same basic block as the accept /
+//     reject / stop decisions (lambda of the step is known from the mode and the old lambda alone), so
+//     the decision chain (error comparison, ||dp|| / ||p|| sums) hides in the solve's latency; a
+//     rejected or terminating trial simply discards the step,
+//   * the damped 9x9 Schur system is solved with row i in lane i by a scaled Gauss-Jordan elimination
+//     (ccal_math.hpp gj_row_step): step j broadcasts pivot row j (one v_mov_b64_dpp row_newbcast per
+//     value) and every other lane does  row_i <- row_i (d s) - (a_ij s) row_j  with s the raw v_rcp_f64
+//     estimate of 1 / d -- four dependent FP64 operations per pivot, no refined reciprocal (square root),
+//     and no back-substitution: after nine steps x_i = b_i / a_ii sits in lane i.
+//     The system is symmetric positive definite (all pivots > 0 is the test Cholesky makes), so no
+//     pivoting is needed; tests/test_acc_host.py checks the same arithmetic against exact rationals.
+// rs = the 68 decoded sums; sS = S0 once more as a full symmetric 9 x 9 (row stride SROW) so that lane i fetches
+// its row with five wide LDS reads.  Uniform values are stored by every lane to the same LDS address; per-parameter values by lanes 0..8.
 // BOOK = true (workgroup 0 only, whose copy is persisted) also keeps the books the host reads:
 // trace, per-trial kinds, counters, the reported relative step.
 template <bool BOOK>
-__device__ __forceinline__ void lm_advance(LmState *__restrict__ st, const double *__restrict__ rs, TraceRec *trace) {
-    // Everything the decision needs is pulled out of LDS in ONE burst of independent reads (the
-    // reduced row, the scalars of the state, both intrinsic vectors): one lane runs this, so every
-    // dependent LDS round trip in the middle of the logic would be paid in full.
-    double r[NRED];
-#pragma unroll
-    for (int o = 0; o < NRED; o++) r[o] = rs[o];
+__device__ __forceinline__ void lm_advance_wave(LmState *__restrict__ st, const double *__restrict__ rs,
+                                                const double *__restrict__ sS, TraceRec *trace, const int lane) {
+    // ---- one burst of LDS reads ----
     const int mode = st->mode;
     const int lam_lg0 = st->lambda_lg10;
-    int lam_lg = lam_lg0;
     const int lg_part = st->lg_partials, iters0 = st->iters, max_iter = st->max_iter, trials0 = st->trials;
+    const int par0 = st->parity;
     const double prev_err = st->prev_err, eps = st->eps, aspect = st->aspect;
-    double ip[9], ic[9];
-    bool freep[9];
+    const double err = rs[RED_ERR], r_dnum = rs[RED_DNUM], r_dden = rs[RED_DDEN], r_bad = rs[RED_BAD];
+    const int la = lane < 9 ? lane : 8;
+    const double ipl = st->intr_prev[la], icl = st->intr_cand[la], dAl = rs[RED_DA + la];
+    // row `la` of S0 and of the right-hand side; fixed parameters arrive as zero rows / columns with dA = 0
+    // (masked where they are produced, in the sweep), exactly like unobservable ones
+    double a[9], b = rs[RED_GS + la];
+    {
+        const double2 *row = reinterpret_cast<const double2 *>(sS + la * SROW);
 #pragma unroll
-    for (int a = 0; a < 9; a++) {
-        ip[a] = st->intr_prev[a];
-        ic[a] = st->intr_cand[a];
-        freep[a] = st->mask[a] != 0 && r[RED_DA + a] > 0.0;   // fixed / unobservable: delta = 0
+        for (int k = 0; k < 4; k++) { const double2 v = row[k]; a[2 * k] = v.x; a[2 * k + 1] = v.y; }
+        a[8] = sS[la * SROW + 8];
     }
-    // the three lambdas a decision can ask for (dynamic table reads issued with the burst)
-    const double lam_up = pow10_lg(st, min(lam_lg0 + 1, 16)), lam_dn = pow10_lg(st, max(lam_lg0 - 1, -16)),
-                 lam_dn2 = pow10_lg(st, max(lam_lg0 - 2, -16)), lam_same = pow10_lg(st, lam_lg0);
-    auto pow10_sel = [&](int lg) -> double {       // 10^lg from the pre-read values when it is one of them
-        return lg == lam_lg0 ? lam_same : (lg == lam_lg0 - 1 ? lam_dn : (lg == lam_lg0 - 2 ? lam_dn2 : (lg == lam_lg0 + 1 ? lam_up : pow10_lg(st, lg))));
-    };
-    const double err = r[RED_ERR];
+    const double lam_same = pow10_lg(st, lam_lg0), lam_up = pow10_lg(st, min(lam_lg0 + 1, 16)),
+                 lam_dn = pow10_lg(st, max(lam_lg0 - 1, -16)), lam_dn2 = pow10_lg(st, max(lam_lg0 - 2, -16));
+    const int lg_dn = max(lam_lg0 - 1, -16);
+#define POW10_SEL(lg) lam_pick((lg), lam_lg0, lg_dn, lam_same, lam_up, lam_dn, lam_dn2)   /* 10^lg for the lambdas a decision can reach */
+    int sweeps0 = 0, rejected0 = 0, reschur0 = 0;
+    if (BOOK) { sweeps0 = st->sweeps; rejected0 = st->rejected; reschur0 = st->reschur; }
+
+    // ---- decisions (wave-uniform, no stores yet) ----
+    const bool is_init = mode == MODE_INIT, is_eval = mode == MODE_EVAL;
+    const bool worse = err > prev_err;
+    const bool reject = is_eval && worse && lam_lg0 + 1 <= 16;
+    const bool accept = is_eval && !reject;
+    // lambda after an accepted step (the ++ of a rejection that could not happen at 10^16 is undone by the --)
+    const int lam_lg_acc = max(lam_lg0 + (worse ? 1 : 0) - 1, -16);
+    const int lam_lg = accept ? lam_lg_acc : lam_lg0;           // lambda exponent of the step solved below
+    const double lam = POW10_SEL(lam_lg);
+    const bool nonfinite = !(fabs(err) < 1.0e300);
+    // ||param - prevParam||^2 and ||prevParam||^2 over the whole parameter vector: the extrinsic part was
+    // summed by the sweep, the nine intrinsic slots are added here (lanes 0..8 of the first row of 16)
+    const double dl = lane < 9 ? icl - ipl : 0.0;
+    const double dnum = r_dnum + lane_bcast(row_sum16(dl * dl), 0);
+    const double dden = r_dden + lane_bcast(row_sum16(lane < 9 ? ipl * ipl : 0.0), 0);
+    const bool small = dnum < eps * eps * dden;     // stop rule ||dp|| / ||p|| < eps without sqrt / divide
+    double rel = 0.0;
+    if (BOOK) rel = sqrt(dnum / dden);
+    const double ip_new = accept ? icl : ipl;       // this lane's accepted intrinsic after the decision
+
+    // ---- step(): damped Schur system  S = A_l - SC = S0 + lambda diag(A),  rhs = g - sg  (row A8) ----
+    STAMP2(0);
+    const bool fi = dAl > 0.0;                      // free and observable (delta = 0 otherwise: identity row)
+    {
+        const double dsel = fi ? fma(lam, dAl, sS[la * SROW + la]) : 1.0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) a[k] = (la == k) ? dsel : a[k];
+    }
+    STAMP2(1);
+    bool ok = true;                                 // (per lane; lane 0's copy decides)
+    double diag = 1.0;                              // this lane's own pivot, rescaled along with its row
+    gj9_steps(a, b, diag, ok, lane, std::integral_constant<int, 0>());
+    ok = (__ballot(ok) & 1ull) != 0;
+    STAMP2(2);
+    // x_i = b_i / a_ii, one correction step on the quotient
+    const double rd = rcp_pos(diag);
+    double x = b * rd;
+    x = fma(fma(-diag, x, b), rd, x);
+    const double dlt = (lane < 9 && fi && ok) ? x : 0.0;
+    double cand = ip_new - dlt;
+    const double cand1 = row_bcast16<1>(cand);
+    if (aspect > 0.0 && lane == 0) cand = aspect * cand1;
+    STAMP2(3);
+
+    // ---- the state machine proper: stores only ----
+    const bool l0 = lane == 0;
     if (BOOK) {
         if (trials0 < MAX_KINDS) st->kinds[trials0] = 1 + mode;
-        st->n_bad = (int)r[RED_BAD];
+        st->n_bad = (int)r_bad;
     }
     st->trials = trials0 + 1;
-    double lam = lam_same;                          // lambda of the step() below
-    if (mode == MODE_INIT) {
-        if (BOOK) { st->sweeps++; lm_trace(st, trace, err, -1.0, 2); }
+    if (is_init) {
+        if (BOOK) {
+            st->sweeps = sweeps0 + 1;
+            if (l0) lm_trace(st, trace, err, -1.0, 2);
+        }
         st->prev_err = err;
-        if (!(fabs(err) < 1.0e300)) { st->status = -4; st->done = 1; return; }
-    } else if (mode == MODE_EVAL) {
-        if (BOOK) st->sweeps++;
-        if (err > prev_err && lam_lg + 1 <= 16) {
+        if (nonfinite) { st->status = -4; st->done = 1; return; }
+    } else if (is_eval) {
+        if (BOOK) st->sweeps = sweeps0 + 1;
+        if (reject) {
             // rejected: sweep the accepted point again with the larger lambda
-            lam_lg++;
-            st->lambda_lg10 = lam_lg;
-            if (BOOK) { st->rejected++; lm_trace(st, trace, err, -1.0, 0); }
+            st->lambda_lg10 = lam_lg0 + 1;
+            if (BOOK) {
+                st->rejected = rejected0 + 1;
+                if (l0) lm_trace(st, trace, err, -1.0, 0);
+            }
             st->mode = MODE_RESCHUR;
-            st->lg_partials = lam_lg;
+            st->lg_partials = lam_lg0 + 1;
             st->lam_next = lam_up;
             return;
         }
-        if (err > prev_err) lam_lg++;               // lambda already at 10^16: the ++ happened, OpenCV accepts the step
-        lam_lg = max(lam_lg - 1, -16);
         st->lambda_lg10 = lam_lg;
         st->iters = iters0 + 1;
-        double dnum = r[RED_DNUM], dden = r[RED_DDEN];
-#pragma unroll
-        for (int a = 0; a < 9; a++) {
-            const double d = ic[a] - ip[a];
-            dnum += d * d;
-            dden += ip[a] * ip[a];
-            ip[a] = ic[a];
-            st->intr_prev[a] = ic[a];
-        }
-        // stop rule ||param - prevParam|| / ||prevParam|| < eps, decided without sqrt / divide
-        const bool small = dnum < eps * eps * dden;
-        st->parity ^= 1;
+        if (lane < 9) st->intr_prev[lane] = icl;
+        st->parity = par0 ^ 1;
         st->prev_err = err;
         if (BOOK) {
-            const double rel = sqrt(dnum / dden);
             st->rel_step = rel;
-            lm_trace(st, trace, err, rel, 1);
+            if (l0) lm_trace(st, trace, err, rel, 1);
         }
-        if (!(fabs(err) < 1.0e300)) { st->status = -4; st->done = 1; return; }
+        if (nonfinite) { st->status = -4; st->done = 1; return; }
         if (iters0 + 1 >= max_iter || small) {
             if (!small) st->status = 1;             // CCAL_W_MAX_ITER
             st->done = 1;
             return;
         }
-        lam = pow10_sel(lam_lg);
-        if (lg_part != lam_lg) {                    // lambda saturated: partials are for another lambda
+        if (lg_part != lam_lg) {                    // lambda saturated: the sums are for another lambda
             st->mode = MODE_RESCHUR;
             st->lg_partials = lam_lg;
             st->lam_next = lam;
             return;
         }
     } else {
-        if (BOOK) st->reschur++;                    // fresh system of the accepted point at the new lambda
+        if (BOOK) st->reschur = reschur0 + 1;       // fresh system of the accepted point at the new lambda
     }
-
-    // ---- step(): damped Schur system  S = A_l - SC = S0 + lambda diag(A),  rhs = g - sg  (row A8) ----
-    STAMP2(0);
-    double S[45], rhs[9], inv[9];
-#pragma unroll
-    for (int a = 0; a < 9; a++) {
-#pragma unroll
-        for (int b = 0; b <= a; b++) {
-            double v = r[RED_S + tri(a, b)];
-            if (a == b) v += lam * r[RED_DA + a];
-            if (!(freep[a] && freep[b])) v = (a == b) ? 1.0 : 0.0;
-            S[tri(a, b)] = v;
-        }
-        rhs[a] = freep[a] ? r[RED_GS + a] : 0.0;
-    }
-    STAMP2(1);
-    const bool ok = chol_packed<9>(S, inv);
-    STAMP2(2);
     if (!ok) {
         // damped system not positive definite (degenerate geometry): damp harder
+        st->lambda_lg10 = lam_lg + 1;
         if (lam_lg + 1 <= 16) {
-            st->lambda_lg10 = lam_lg + 1;
             st->mode = MODE_RESCHUR;
             st->lg_partials = lam_lg + 1;
-            st->lam_next = pow10_sel(lam_lg + 1);
+            st->lam_next = POW10_SEL(lam_lg + 1);
         } else {
-            st->lambda_lg10 = lam_lg + 1;
             st->status = -3;
             st->done = 1;
         }
         return;
     }
-    fwd_subst<9>(S, inv, rhs);
-    bwd_subst<9>(S, inv, rhs);
-    STAMP2(3);
-    double cand[9];
-#pragma unroll
-    for (int a = 0; a < 9; a++) {
-        const double d = freep[a] ? rhs[a] : 0.0;
-        st->dint[a] = d;
-        cand[a] = ip[a] - d;
+    if (lane < 9) {
+        st->dint[lane] = dlt;
+        st->intr_cand[lane] = cand;
     }
-    if (aspect > 0.0) cand[0] = aspect * cand[1];
-#pragma unroll
-    for (int a = 0; a < 9; a++) st->intr_cand[a] = cand[a];
     st->lam_step = lam;
     const int lgn = max(lam_lg - 1, -16);
     st->lg_partials = lgn;
-    st->lam_next = pow10_sel(lgn);
+    st->lam_next = POW10_SEL(lgn);
     st->mode = MODE_EVAL;
+#undef POW10_SEL
 }
 
 // wave-private LDS carve-up (doubles).  The Gram tile is dead once the MFMAs have issued, so
 // everything after it re-uses the same 17 KB.
 constexpr int W_G = 0;        // 16 x 16 Gram matrix
-constexpr int W_HEAD = 256;   // 72-double block head (prologue staging, then the new head)
-constexpr int W_Y = 328;      // Y[j][k] = (L^-1 col_j)[k], 10 x 6
+constexpr int W_HEAD = 256;   // the image's new 128-double block
+constexpr int W_Y = 384;      // Y[j][k] = (L^-1 col_j)[k], 10 x 6
 static_assert(W_Y + 60 <= TILE_D, "wave scratch exceeds the tile");
 
 constexpr int STATE_WORDS = sizeof(LmState) / 8;
 static_assert(sizeof(LmState) % 8 == 0, "LmState is copied as 8-byte words");
 static_assert(HOST_WORDS <= 64 && HOST_WORDS <= STATE_WORDS, "host mirror is written by one wave");
-constexpr int RED_PAIRS = NRED / 2;                 // partial rows are read as 34 double2
-constexpr int RED_SLICES = (WAVES * 64) / RED_PAIRS; // 7 slices of rows per workgroup
-constexpr int RED_UNROLL = 40;                      // double2 loads in flight per thread (280 rows in one trip)
+constexpr int ACC_PAIRS = ACC_ROW / 2;              // one replica is read as 170 16-byte pairs
+static_assert(STATE_WORDS <= WAVES * 64 && ACC_PAIRS <= WAVES * 64, "one load per thread covers the state / a replica");
+static_assert(ACC_ROW % 2 == 0, "replicas are read as 16-byte pairs");
 
-// Fixed-order sum of `n_rows` rows of NRED doubles by one 256-thread workgroup -> rs[NRED].
-// Slice c adds rows c, c + 7, ...; the first RED_UNROLL rows of every slice are fetched by
-// reduce_issue() as independent 16-byte loads BEFORE anything waits on memory, so the prologue
-// costs one memory round trip for up to 7 * RED_UNROLL rows; slices are combined in order.
-// Same instruction order on the same data in every workgroup: identical bits everywhere.
-struct RedRegs { double2 v[RED_UNROLL]; };
+// Reading the exact accumulators (ccal_acc.hpp) of one trial: thread t < 170 owns the 16-byte pair t of
+// every replica; all loads are issued before anything waits on memory (one round trip), the replicas are
+// added as split integer sums (no overflow for any grid size) and left in LDS for acc_row_decode().
+struct AccRegs { AccPart p0, p1; };
 
-__device__ __forceinline__ void reduce_issue(const double *__restrict__ rows, int n_rows, int tid, RedRegs &q) {
-    const int j2 = tid % RED_PAIRS, c = tid / RED_PAIRS;
-    const double2 *src = reinterpret_cast<const double2 *>(rows) + j2;
+__device__ __forceinline__ void acc_read_issue(const long long *__restrict__ acc, int R, int tid, AccRegs &q) {
+    q.p0.hi = q.p0.lo = q.p1.hi = q.p1.lo = 0.0;
+    if (tid >= ACC_PAIRS) return;
+    const longlong2 *src = reinterpret_cast<const longlong2 *>(acc) + tid;
+    for (int r0 = 0; r0 < R; r0 += 8) {
+        longlong2 v[8];
 #pragma unroll
-    for (int k = 0; k < RED_UNROLL; k++) {
-        const int r = c + k * RED_SLICES;
-        q.v[k] = (c < RED_SLICES && r < n_rows) ? src[(size_t)r * RED_PAIRS] : make_double2(0.0, 0.0);
+        for (int r = 0; r < 8; r++) v[r] = (r0 + r < R) ? src[(size_t)(r0 + r) * ACC_PAIRS] : make_longlong2(0, 0);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            acc_part_add(q.p0, v[r].x);
+            acc_part_add(q.p1, v[r].y);
+        }
     }
 }
 
-__device__ __forceinline__ void reduce_finish(const double *__restrict__ rows, int n_rows, double *part, double *rs,
-                                              int tid, const RedRegs &q) {
-    const int j2 = tid % RED_PAIRS, c = tid / RED_PAIRS;
-    if (c < RED_SLICES) {
-        double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < RED_UNROLL; k++) { s0 += q.v[k].x; s1 += q.v[k].y; }
-        const double2 *src = reinterpret_cast<const double2 *>(rows) + j2;
-        for (int r0 = c + RED_UNROLL * RED_SLICES; r0 < n_rows; r0 += RED_SLICES * 8) {   // beyond the first group
-            double2 v[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int r = r0 + k * RED_SLICES;
-                v[k] = r < n_rows ? src[(size_t)r * RED_PAIRS] : make_double2(0.0, 0.0);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) { s0 += v[k].x; s1 += v[k].y; }
-        }
-        part[c * NRED + 2 * j2] = s0;
-        part[c * NRED + 2 * j2 + 1] = s1;
+__device__ __forceinline__ void acc_read_stage(AccPart *s_acc, int tid, const AccRegs &q) {
+    if (tid < ACC_PAIRS) {
+        s_acc[2 * tid] = q.p0;
+        s_acc[2 * tid + 1] = q.p1;
     }
-    __syncthreads();
-    if (tid < NRED) {
-        double t = part[tid];
+}
+
+// column `col` of the staged sums -> double (threads 0..67, after a barrier).  The pad column carries the
+// flags: a NaN contribution anywhere makes the error NaN, an out-of-range one makes it +inf, so the
+// state machine rejects (or aborts on) such a trial exactly as it does for a non-finite error.
+__device__ __forceinline__ double acc_row_decode(const AccPart *s_acc, int col) {
+    AccPart part[ACC_LIMBS];
 #pragma unroll
-        for (int k = 1; k < RED_SLICES; k++) t += part[k * NRED + tid];
-        rs[tid] = t;
+    for (int j = 0; j < ACC_LIMBS; j++) part[j] = s_acc[j * NRED + col];
+    double v = acc_decode(part);
+    const AccPart n_nan = s_acc[0 * NRED + ACC_FLAG_COL], n_big = s_acc[1 * NRED + ACC_FLAG_COL];
+    if (col == ACC_FLAG_COL) v = 0.0;
+    if (col == RED_ERR) {
+        if (n_big.hi != 0.0 || n_big.lo != 0.0) v = __longlong_as_double(0x7ff0000000000000ll);
+        if (n_nan.hi != 0.0 || n_nan.lo != 0.0) v = __longlong_as_double(0x7ff8000000000000ll);
     }
-    __syncthreads();
+    return v;
+}
+
+// this workgroup's 68 sums -> limbs -> integer atomics into one replica (threads 0..67)
+__device__ __forceinline__ void acc_add(long long *__restrict__ dst, int col, double v) {
+    int j, flag;
+    int64_t lo, hi;
+    acc_split(v, j, lo, hi, flag);
+#ifdef CCAL_EXP_STORE_NOT_ATOMIC   // timing experiment only (wrong sums): what the atomics cost against plain stores
+    dst[j * NRED + col] = lo;
+    dst[(j + 1) * NRED + col] = hi;
+    return;
+#endif
+    if (flag) {
+        __hip_atomic_fetch_add(dst + (flag - 1) * NRED + ACC_FLAG_COL, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (lo != 0) __hip_atomic_fetch_add(dst + j * NRED + col, (long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hi != 0) __hip_atomic_fetch_add(dst + (j + 1) * NRED + col, (long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// clear `n_bufs` consecutive accumulator buffers (one workgroup, plain 16-byte stores)
+__device__ __forceinline__ void acc_clear(long long *__restrict__ acc, int R, int n_bufs, int tid) {
+    longlong2 *dst = reinterpret_cast<longlong2 *>(acc);
+    const int n = n_bufs * R * ACC_PAIRS;
+    for (int i = tid; i < n; i += WAVES * 64) dst[i] = make_longlong2(0, 0);
 }
 
 // Everything one launch needs, by value (a solve is a graph of these launches).
@@ -308,9 +413,11 @@ struct TrialArgs {
     const float *obj, *img;
     double *blk;
     LmState *st;                  // [2], double-buffered by trial parity: S_k lives in st[k & 1]
-    double *partials;             // [2][nblocks][NRED], this trial writes buffer k & 1
-    const double *rows_in;        // reduction input of the prologue (previous partials, or reduced rows)
-    int n_in;
+    long long *acc;               // [3][R][ACC_ROW] exact accumulators: this trial adds into buffer k % 3,
+                                  // its prologue reads buffer (k - 1) % 3, workgroup 0 clears buffer (k + 1) % 3
+    int R;                        // replicas per buffer
+    const double *row_in;         // != NULL: the prologue takes the reduced system from this row of 68 doubles
+                                  // (already summed across GPUs by RCCL / a host hook / k_lm_exchange) instead
     TraceRec *trace;
     LmState *host_result;
     unsigned long long *host_progress;
@@ -366,38 +473,52 @@ template <bool XCHG>
 __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
     __shared__ __attribute__((aligned(16))) double s_wave[WAVES * TILE_D];
     __shared__ __attribute__((aligned(16))) double s_red[WAVES * NRED];
-    __shared__ __attribute__((aligned(16))) double s_part[RED_SLICES * NRED];
     __shared__ __attribute__((aligned(16))) double s_rs[NRED];
+    __shared__ __attribute__((aligned(16))) double s_S[9 * SROW];
     __shared__ LmState ls;
     double *s_all = s_wave;       // XCHG: the peers' rows are staged in the (not yet used) tile space
-    static_assert(P2P_MAX_RANKS * NRED <= WAVES * TILE_D, "exchange staging exceeds the tile space");
+    AccPart *s_acc = reinterpret_cast<AccPart *>(s_wave + P2P_MAX_RANKS * NRED);   // staged accumulator sums, likewise
+    static_assert(P2P_MAX_RANKS * NRED + 2 * ACC_ROW <= WAVES * TILE_D, "prologue staging exceeds the tile space");
 
     const int tid = threadIdx.x;
     STAMP(0);
+    STAMP_RT(30);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = A.N, P = A.P;
     const int img_i = blockIdx.x * WAVES + wave;
     const bool active = img_i < N;              // wave-uniform
     const int ii = active ? img_i : N - 1;      // clamped: idle waves mirror the last image, store nothing
+    const size_t acc_buf = (size_t)A.R * ACC_ROW;   // int64 words per accumulator buffer
 
-    // ---- 0. loads that do not depend on the LM state are issued up front: both parities of the
-    //         block head (rvec,tvec | U | pd) -- or the start pose -- and the first 64 corners ----
-    double h0a = 0.0, h1a = 0.0, h0b = 0.0, h1b = 0.0;
+    // ---- 0. loads that do not depend on the LM state are issued up front: the previous state, the
+    //         accumulators of the previous trial, both parities of the block head (rvec,tvec | U | pd)
+    //         -- or the start pose -- and the first 64 corners ----
+    const LmState *prev = A.st + ((A.k - 1) & 1);
+    double sw = 0.0, row_v = 0.0;
+    AccRegs q;
+    if (!A.first) {
+        if (tid < STATE_WORDS) sw = reinterpret_cast<const double *>(prev)[tid];
+        if (A.row_in != nullptr) { if (tid < NRED) row_v = A.row_in[tid]; }
+        else acc_read_issue(A.acc + (size_t)((A.k + 2) % 3) * acc_buf, A.R, tid, q);
+    }
+    double h0a = 0.0, h1a = 0.0, h0b = 0.0, h1b = 0.0;   // block words lane (a) and 64 + lane (b) of parity 0 / 1
     const float2 *img2 = reinterpret_cast<const float2 *>(A.img) + (size_t)ii * P;
     const int pc0 = lane < P ? lane : P - 1;
     float2 uv = make_float2(0.f, 0.f);
     float m0 = 0.f, m1 = 0.f, m2 = 0.f;
     if (!A.final_only) {
         if (A.first) {
-            h0a = lane < 6 ? A.ext0[(size_t)ii * A.ext0_stride + lane] : 0.0;
+            h0b = (lane >= BLK_EXT - 64 && lane < BLK_EXT - 64 + 6) ? A.ext0[(size_t)ii * A.ext0_stride + lane - (BLK_EXT - 64)] : 0.0;
         } else {
             const double *b0p = A.blk + (size_t)ii * BLK, *b1p = A.blk + ((size_t)N + ii) * BLK;
             h0a = b0p[lane]; h1a = b1p[lane];
-            if (lane < 8) { h0b = b0p[64 + lane]; h1b = b1p[64 + lane]; }
+            h0b = b0p[64 + lane]; h1b = b1p[64 + lane];
         }
         uv = img2[pc0];                         // coalesced 8 B per lane
         m0 = A.obj[3 * pc0]; m1 = A.obj[3 * pc0 + 1]; m2 = A.obj[3 * pc0 + 2];
+        // the buffer the NEXT trial adds into was last read one launch ago: clear it now
+        if (blockIdx.x == 0) acc_clear(A.acc + (size_t)((A.k + 1) % 3) * acc_buf, A.R, 1, tid);
     }
     int oa, ob;                                 // (a, b) of the packed S0 entry this lane assembles
     tri_decode(lane < 45 ? lane : 0, oa, ob);
@@ -412,40 +533,56 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
             if (blockIdx.x == 0 && tid == 0)
                 __hip_atomic_store(A.p2p.epoch, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-        const LmState *prev = A.st + ((A.k - 1) & 1);
-        RedRegs q;
-        reduce_issue(A.rows_in, A.n_in, tid, q);   // in flight together with the state and the heads
-        for (int i = tid; i < STATE_WORDS; i += WAVES * 64)
-            reinterpret_cast<double *>(&ls)[i] = reinterpret_cast<const double *>(prev)[i];
+        if (tid < STATE_WORDS) reinterpret_cast<double *>(&ls)[tid] = sw;
+        if (A.row_in != nullptr) {
+            if (tid < NRED) s_rs[tid] = row_v;
+            if (tid < RED_DA) { s_S[oa * SROW + ob] = row_v; s_S[ob * SROW + oa] = row_v; }
+        } else {
+            acc_read_stage(s_acc, tid, q);
+        }
         __syncthreads();
         STAMP(11);
         if (ls.done) {
             // solve already terminated: surplus launch.  The terminal state is carried along, so every
-            // later launch of the batch sees it too (none of them sweeps or exchanges again).
+            // later launch of the batch sees it too (none of them sweeps or exchanges again); the
+            // terminating launch leaves all accumulators cleared for the next solve.
             if (blockIdx.x == 0) {
                 LmState *cur = A.st + (A.k & 1);
-                for (int i = tid; i < STATE_WORDS; i += WAVES * 64)
-                    reinterpret_cast<double *>(cur)[i] = reinterpret_cast<const double *>(&ls)[i];
+                if (tid < STATE_WORDS) reinterpret_cast<double *>(cur)[tid] = reinterpret_cast<const double *>(&ls)[tid];
+                if (A.final_only) acc_clear(A.acc, A.R, ACC_BUFS, tid);
             }
             return;
         }
-        reduce_finish(A.rows_in, A.n_in, s_part, s_rs, tid, q);
+        if (A.row_in == nullptr) {
+            if (tid < NRED) {
+                const double v = acc_row_decode(s_acc, tid);
+                s_rs[tid] = v;
+                if (tid < RED_DA) { s_S[oa * SROW + ob] = v; s_S[ob * SROW + oa] = v; }   // (tid == lane of wave 0)
+            }
+            __syncthreads();
+        }
         if constexpr (XCHG)
-            if (A.xchg_fused)
+            if (A.xchg_fused) {
                 p2p_exchange_rows(A.p2p, p2p_tag(seq, (unsigned)A.k), p2p_slot(seq, (unsigned)A.k), s_rs, s_all, NRED, tid,
                                   blockIdx.x == 0);
+                if (tid < RED_DA) {               // the symmetric copy again, now of the sum over the ranks (wave 0 only)
+                    const double v = s_rs[tid];
+                    s_S[oa * SROW + ob] = v;
+                    s_S[ob * SROW + oa] = v;
+                }
+                if (wave == 0) wave_lds_sync();
+            }
         STAMP(12);
-        if (tid == 0) {
-            if (blockIdx.x == 0) lm_advance<true>(&ls, s_rs, A.trace);
-            else lm_advance<false>(&ls, s_rs, nullptr);
+        if (wave == 0) {
+            if (blockIdx.x == 0) lm_advance_wave<true>(&ls, s_rs, s_S, A.trace, lane);
+            else lm_advance_wave<false>(&ls, s_rs, s_S, nullptr, lane);
         }
         __syncthreads();
     }
     STAMP(1);
     if (blockIdx.x == 0) {
         LmState *cur = A.st + (A.k & 1);
-        for (int i = tid; i < STATE_WORDS; i += WAVES * 64)
-            reinterpret_cast<double *>(cur)[i] = reinterpret_cast<const double *>(&ls)[i];
+        if (tid < STATE_WORDS) reinterpret_cast<double *>(cur)[tid] = reinterpret_cast<const double *>(&ls)[tid];
         if (A.host_progress != nullptr && tid < 64) {
             // wave 0 alone talks to the host: the state header when the solve terminates, then the
             // progress word (trials << 32) | done that the host spins on, released at system scope
@@ -456,6 +593,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
                                    ((unsigned long long)(unsigned)ls.trials << 32) | (ls.done ? 1ull : 0ull),
                                    __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
+        // the terminating launch of a finished solve leaves every accumulator cleared (its own input was
+        // consumed before the barrier above); an unfinished one keeps its input for the trial that follows
+        if (A.final_only && ls.done) acc_clear(A.acc, A.R, ACC_BUFS, tid);
     }
     if (ls.done || A.final_only) return;
 
@@ -468,8 +608,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
     double *red = s_red + wave * NRED;
 
     // ---- 2. block head of the accepted point -> wave-uniform registers ----
-    // lane j holds head[j] (hsel) and lanes 0..7 head[64 + j] (hselb); uniform values are pulled out
-    // with v_readlane, no LDS staging of the head
+    // lane j holds block word j (hsel) and word 64 + j (hselb); uniform values are pulled out with
+    // v_readlane, no LDS staging of the block
     const double hsel = par ? h1a : h0a, hselb = par ? h1b : h0b;
     auto bcast = [](double v, int src) -> double {
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
@@ -477,30 +617,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
     };
     double e6[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) e6[k] = bcast(hsel, BLK_EXT + k);
+    for (int k = 0; k < 6; k++) e6[k] = bcast(hselb, BLK_EXT - 64 + k);
     double dnum = 0.0, dden = 0.0;
     double in[NINTR];
     if (mode == MODE_EVAL) {
-        // delta_i = C_l^-1 (h - B^T delta_int) = u_h - U_B delta_int, U kept by the last sweep: lane
-        // 8 + 6a + k multiplies U[a][k] by delta_int[a]; the products (and u_h, head[62..67]) are
-        // transposed through LDS so that lane k < 6 adds up component k
-        static_assert(BLK_U == 8 && BLK_PD == 68, "head layout");
-        const bool isU = lane >= BLK_U && lane < BLK_U + 54;
-        const double da = isU ? ls.dint[(lane - BLK_U) / 6] : 1.0;
-        Hs[lane] = hsel * da;
-        if (lane < 4) Hs[64 + lane] = hselb;
-        wave_lds_sync();
-        double dl = 0.0;
-        if (lane < 6) {
-            double acc = 0.0;
-#pragma unroll
-            for (int a = 0; a < NINTR; a++) acc += Hs[BLK_U + a * 6 + lane];
-            dl = Hs[BLK_U + 54 + lane] - acc;
-        }
+        // delta_i = C_l^-1 (h - B^T delta_int) = u_h - U_B delta_int, U kept by the last sweep one value per
+        // lane: lane 16 k + j multiplies U[j][k] by (-delta_int[j] | +1 for j = 9 | 0), a DPP sum inside each row
+        // of 16 lanes leaves component k in row k (k = 0..3: first block word; k = 4, 5: second one)
+        const int j16 = lane & 15;
+        const double mj = j16 < NINTR ? -ls.dint[j16 < NINTR ? j16 : 0] : (j16 == NINTR ? 1.0 : 0.0);
+        const double sA = row_sum16(hsel * mj);
+        const double sB = row_sum16(lane < 32 ? hselb * mj : 0.0);
         const bool ok = bcast(hselb, BLK_PD - 64) != 0.0;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            const double dk = ok ? bcast(dl, k) : 0.0;    // degenerate view: leave its pose unchanged
+            const double dl = k < 4 ? bcast(sA, 16 * k) : bcast(sB, 16 * (k - 4));
+            const double dk = ok ? dl : 0.0;              // degenerate view: leave its pose unchanged
             dden += e6[k] * e6[k];
             dnum += dk * dk;
             e6[k] -= dk;
@@ -513,6 +645,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
         for (int a = 0; a < NINTR; a++) in[a] = ls.intr_prev[a];
     }
     const double aspect = ls.aspect, lam_next = ls.lam_next;
+    // does the reduced-system entry this lane will assemble belong to free parameters only?
+    // lanes 0..44: S0(oa, ob); 45..53: dA(a); 54..62: gs(a); 63: the error
+    const int ka = lane < RED_DA ? oa : (lane < RED_ERR ? (lane - RED_DA) % NINTR : 0);
+    const int kb = lane < RED_DA ? ob : ka;
+    const bool keep = lane >= RED_ERR || (ls.mask[ka] != 0 && ls.mask[kb] != 0);
     wave_lds_sync();                              // head consumed: the tile may overwrite it
 
     // ---- 3. rows -> LDS -> f64 MFMA Gram ----
@@ -557,43 +694,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
         for (int b = 0; b <= a; b++) C[tri(a, b)] = Gs[a * 16 + b];   // LDS broadcast reads
     damp_diag<6>(C, lam_next);
     const bool pd = chol_packed<6>(C, inv);
+    // lane j < 10 owns column j of [B^T | h]
+    const int yj = lane < 10 ? lane : 9;
+    double y[6];
     {
-        // lane j < 10 owns column j of [B^T | h]
-        const int j = lane < 10 ? lane : 9;
-        const int col = j < 9 ? 6 + j : COL_E;
-        double y[6];
+        const int col = yj < 9 ? 6 + yj : COL_E;
 #pragma unroll
         for (int k = 0; k < 6; k++) y[k] = Gs[k * 16 + col];
         fwd_subst<6>(C, inv, y);
         if (lane < 10) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) Ys[j * 6 + k] = y[k];
-        }
-        bwd_subst<6>(C, inv, y);
-        if (lane < 10) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) Hs[BLK_U + j * 6 + k] = y[k];
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) Hs[BLK_EXT + k] = e6[k];
-            Hs[6] = Hs[7] = 0.0;
-            Hs[BLK_PD] = pd ? 1.0 : 0.0;
-            Hs[69] = Hs[70] = Hs[71] = 0.0;
+            for (int k = 0; k < 6; k++) Ys[yj * 6 + k] = y[k];
         }
     }
     wave_lds_sync();
 
-    // ---- keep this image's block for the next sweep's prologue ----
+    // ---- this image's contributions to the reduced system: S0 | dA | gs | err dnum dden bad.  They go
+    //      first: their atomics are the only thing the next launch waits for, everything after them
+    //      (U, the block store) is local and runs while they are in flight ----
     STAMP(8);
-    if (active) {
-        double *bo = A.blk + ((size_t)cand * N + ii) * BLK;
-        bo[lane] = Hs[lane];
-        if (lane < 8) bo[64 + lane] = Hs[64 + lane];
-    }
-
-    // ---- this image's contributions to the reduced system: S0 | dA | gs | err dnum dden bad ----
-    STAMP(9);
     const double err_i = Gs[COL_E * 16 + COL_E];
     const bool finite = (err_i == err_i) && (fabs(err_i) < 1.0e300);
     {
@@ -617,7 +736,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
         } else {
             v = err_i;                                    // lane 63
         }
-        red[lane] = active ? v : 0.0;
+        red[lane] = (active && keep) ? v : 0.0;   // fixed parameters leave zero rows / columns, dA = 0 and g = 0
         if (lane < 4) {
             const double w = lane == 0 ? dnum : (lane == 1 ? dden : (lane == 2 ? ((pd && finite) ? 0.0 : 1.0) : 0.0));
             red[64 + lane] = active ? w : 0.0;
@@ -627,10 +746,33 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
     if (tid < NRED) {
         double s = s_red[tid];
 #pragma unroll
-        for (int w = 1; w < WAVES; w++) s += s_red[w * NRED + tid];   // fixed order
-        A.partials[((size_t)(A.k & 1) * gridDim.x + blockIdx.x) * NRED + tid] = s;
+        for (int w = 1; w < WAVES; w++) s += s_red[w * NRED + tid];   // fixed order inside the workgroup
+        // ... and exact, order-independent across workgroups: limbs added with integer atomics
+        acc_add(A.acc + ((size_t)(A.k % 3) * A.R + (blockIdx.x & (A.R - 1))) * ACC_ROW, tid, s);
+    }
+    STAMP(9);
+
+    // ---- U = L^-T Y and this image's block for the next sweep's back-substitution ----
+    bwd_subst<6>(C, inv, y);
+    Hs[lane] = 0.0;                               // (the DS unit keeps one wave's writes in order)
+    Hs[64 + lane] = 0.0;
+    if (lane < 10) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) Hs[(k < 4 ? 16 * k : 64 + 16 * (k - 4)) + yj] = y[k];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) Hs[BLK_EXT + k] = e6[k];
+        Hs[BLK_PD] = pd ? 1.0 : 0.0;
+    }
+    wave_lds_sync();
+    if (active) {
+        double *bo = A.blk + ((size_t)cand * N + ii) * BLK;
+        bo[lane] = Hs[lane];
+        bo[64 + lane] = Hs[64 + lane];
     }
     STAMP(10);
+    STAMP_RT(31);
 }
 
 #ifdef CCAL_STAMPS
@@ -640,85 +782,42 @@ hipError_t debug_read_stamps(unsigned long long *out) {
 #endif
 
 // ---------------------------------------------------------------------------------------
-// partial rows -> G rows (row g = fixed-order sum of rows g, g + G, ...)
+// accumulators of trial k - 1 -> one row of 68 doubles (one workgroup); used when a collective
+// library or a host hook sums the row across GPUs between two trials.  Does nothing once the
+// solve has terminated.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WAVES * 64) void k_lm_reduce(const double *__restrict__ rows, int n_rows,
-                                                           double *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) double s_part[RED_SLICES * NRED];
-    __shared__ __attribute__((aligned(16))) double s_rs[NRED];
-    const int G = gridDim.x, g = blockIdx.x;
-    const int n_mine = (n_rows - g + G - 1) / G;
-    // rows g, g + G, ... are a strided view: same kernel as the prologue with a row stride of G
+__global__ __launch_bounds__(WAVES * 64) void k_lm_row(const long long *__restrict__ acc, int R, const LmState *__restrict__ st,
+                                                        int k, double *__restrict__ out) {
+    __shared__ AccPart s_acc[ACC_ROW];
     const int tid = threadIdx.x;
-    const int j2 = tid % RED_PAIRS, c = tid / RED_PAIRS;
-    if (c < RED_SLICES) {
-        double s0 = 0.0, s1 = 0.0;
-        const double2 *src = reinterpret_cast<const double2 *>(rows) + j2;
-        for (int r0 = c; r0 < n_mine; r0 += RED_SLICES * RED_UNROLL) {
-            double2 v[RED_UNROLL];
-#pragma unroll
-            for (int k = 0; k < RED_UNROLL; k++) {
-                const int r = r0 + k * RED_SLICES;
-                v[k] = r < n_mine ? src[((size_t)r * G + g) * RED_PAIRS] : make_double2(0.0, 0.0);
-            }
-#pragma unroll
-            for (int k = 0; k < RED_UNROLL; k++) { s0 += v[k].x; s1 += v[k].y; }
-        }
-        s_part[c * NRED + 2 * j2] = s0;
-        s_part[c * NRED + 2 * j2 + 1] = s1;
-    }
+    if (__hip_atomic_load(&st[(k - 1) & 1].done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    AccRegs q;
+    acc_read_issue(acc + (size_t)((k + 2) % 3) * R * ACC_ROW, R, tid, q);
+    acc_read_stage(s_acc, tid, q);
     __syncthreads();
-    if (tid < NRED) {
-        double t = s_part[tid];
-#pragma unroll
-        for (int k = 1; k < RED_SLICES; k++) t += s_part[k * NRED + tid];
-        out[(size_t)g * NRED + tid] = t;
-    }
-    (void)s_rs;
+    if (tid < NRED) out[tid] = acc_row_decode(s_acc, tid);
 }
 
 // ---------------------------------------------------------------------------------------
-// multi-GPU: partial rows -> one row -> sum over the ranks of the node (xGMI exchange,
-// ccal_p2p.hpp) -> out[0..68).  ONE workgroup of 1024 threads: 30 slices x 34 column pairs pull
-// the local rows with every load in flight at once (a hand-off between workgroups -- release
-// fence + counter -- costs more than the 136 KB a single CU has to read), combine in fixed
-// order and run the exchange.  Used only when there are too many partial rows for every
-// workgroup of k_lm_trial to sum them (then the exchange is fused into its prologue instead).
+// multi-GPU with many workgroups per rank: accumulators -> one row -> sum over the ranks of the node
+// (xGMI exchange, ccal_p2p.hpp) -> out[0..68), one workgroup, so that thousands of workgroups do not
+// each poll the inbox (few workgroups: the exchange is fused into k_lm_trial's prologue instead).
+// Does nothing once the solve has terminated -- the peers stop exchanging at the same trial, since
+// every rank advances the same state.
 // ---------------------------------------------------------------------------------------
-constexpr int XCH_THREADS = 1024;
-constexpr int XCH_SLICES = 30;      // 30 * RED_PAIRS = 1020 active threads
-constexpr int XCH_UNROLL = 9;       // 270 rows per pass
-
-__global__ __launch_bounds__(XCH_THREADS) void k_lm_exchange(const double *__restrict__ rows, int n_rows,
-                                                              double *__restrict__ out, P2PDev p, int k) {
-    __shared__ __attribute__((aligned(16))) double s_part[XCH_SLICES * NRED];
+__global__ __launch_bounds__(WAVES * 64) void k_lm_exchange(const long long *__restrict__ acc, int R, const LmState *__restrict__ st,
+                                                             double *__restrict__ out, P2PDev p, int k) {
+    __shared__ AccPart s_acc[ACC_ROW];
     __shared__ double s_val[NRED];
     __shared__ double s_all[P2P_MAX_RANKS * NRED];
     const int tid = threadIdx.x;
-    const int j2 = tid % RED_PAIRS, c = tid / RED_PAIRS;
-    if (c < XCH_SLICES) {
-        double s0 = 0.0, s1 = 0.0;
-        const double2 *src = reinterpret_cast<const double2 *>(rows) + j2;
-        for (int r0 = c; r0 < n_rows; r0 += XCH_SLICES * XCH_UNROLL) {
-            double2 v[XCH_UNROLL];
-#pragma unroll
-            for (int k = 0; k < XCH_UNROLL; k++) {
-                const int r = r0 + k * XCH_SLICES;
-                v[k] = r < n_rows ? src[(size_t)r * RED_PAIRS] : make_double2(0.0, 0.0);
-            }
-#pragma unroll
-            for (int k = 0; k < XCH_UNROLL; k++) { s0 += v[k].x; s1 += v[k].y; }
-        }
-        s_part[c * NRED + 2 * j2] = s0;
-        s_part[c * NRED + 2 * j2 + 1] = s1;
-    }
+    if (__hip_atomic_load(&st[(k - 1) & 1].done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;   // a peer already timed out
+    AccRegs q;
+    acc_read_issue(acc + (size_t)((k + 2) % 3) * R * ACC_ROW, R, tid, q);
+    acc_read_stage(s_acc, tid, q);
     __syncthreads();
-    if (tid < NRED) {
-        double t = s_part[tid];
-#pragma unroll
-        for (int k = 1; k < XCH_SLICES; k++) t += s_part[k * NRED + tid];
-        s_val[tid] = t;
-    }
+    if (tid < NRED) s_val[tid] = acc_row_decode(s_acc, tid);
     __syncthreads();
     const unsigned int seq = __hip_atomic_load(p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     p2p_exchange_rows(p, p2p_tag(seq, (unsigned)k), p2p_slot(seq, (unsigned)k), s_val, s_all, NRED, tid, true);
@@ -731,9 +830,10 @@ __global__ __launch_bounds__(XCH_THREADS) void k_lm_exchange(const double *__res
 int lm_sweep_blocks(int N) { return (N + WAVES - 1) / WAVES; }
 
 hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
+    if (t.acc == nullptr || t.R < 1 || t.R > ACC_MAX_REPLICAS || (t.R & (t.R - 1)) != 0) return hipErrorInvalidValue;
     TrialArgs a;
-    a.obj = t.obj; a.img = t.img; a.blk = t.blk; a.st = t.st; a.partials = t.partials;
-    a.rows_in = t.rows_in; a.n_in = t.n_in; a.trace = t.trace; a.host_result = t.host_result;
+    a.obj = t.obj; a.img = t.img; a.blk = t.blk; a.st = t.st; a.acc = t.acc; a.R = t.R;
+    a.row_in = t.row_in; a.trace = t.trace; a.host_result = t.host_result;
     a.host_progress = t.host_progress; a.intr0 = t.intr0; a.ext0 = t.ext0; a.ext0_stride = t.ext0_stride;
     a.init = t.init; a.gram_out = t.gram_out; a.N = t.N; a.P = t.P; a.k = t.k; a.first = t.first;
     a.final_only = t.final_only;
@@ -756,14 +856,23 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     return hipGetLastError();
 }
 
-hipError_t launch_lm_reduce(hipStream_t stream, const double *rows, int n_rows, double *out, int G) {
-    hipLaunchKernelGGL(k_lm_reduce, dim3(G), dim3(WAVES * 64), 0, stream, rows, n_rows, out);
+hipError_t launch_lm_row(hipStream_t stream, const long long *acc, int R, const LmState *st, int k, double *out) {
+    hipLaunchKernelGGL(k_lm_row, dim3(1), dim3(WAVES * 64), 0, stream, acc, R, st, k, out);
     return hipGetLastError();
 }
 
-hipError_t launch_lm_exchange(hipStream_t stream, const double *rows, int n_rows, double *out, const P2PDev &p, int k) {
-    hipLaunchKernelGGL(k_lm_exchange, dim3(1), dim3(XCH_THREADS), 0, stream, rows, n_rows, out, p, k);
+hipError_t launch_lm_exchange(hipStream_t stream, const long long *acc, int R, const LmState *st, double *out, const P2PDev &p,
+                              int k) {
+    hipLaunchKernelGGL(k_lm_exchange, dim3(1), dim3(WAVES * 64), 0, stream, acc, R, st, out, p, k);
     return hipGetLastError();
+}
+
+// replicas per accumulator buffer for a grid of `nblocks` workgroups: 8 unless that would put more than
+// ACC_MAX_ADDS adds on one address per trial
+int lm_acc_replicas(int nblocks) {
+    int R = 8;
+    while (R < ACC_MAX_REPLICAS && (nblocks + R - 1) / R > ACC_MAX_ADDS) R *= 2;
+    return R;
 }
 
 }  // namespace ccal

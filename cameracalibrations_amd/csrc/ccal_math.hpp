@@ -323,6 +323,29 @@ CCAL_HD void damp_diag(double A[N * (N + 1) / 2], double lambda) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Scaled Gauss-Jordan elimination of an SPD system [A | b] without an exact reciprocal, one matrix
+// row per caller (the device keeps row i in lane i and broadcasts the pivot row; tests/host_shim_acc.cpp
+// loops over the rows).  Step j, for a row that is NOT the pivot row:
+//     row <- row * (d s) - (row[j] s) * pivot_row          d = pivot, s ~ 1 / d
+// Column j is eliminated because (row[j] s) / (d s) = row[j] / d whatever s is, so s only has to keep
+// the magnitudes put: the raw v_rcp_f64 estimate does (no Newton refinement on the dependent chain);
+// the two extra roundings are of the size every elimination step makes anyway.  The pivot row itself is
+// left alone (`mine`).  `diag` follows this row's own pivot through the later rescalings, so that at the
+// end x = b / diag.
+// ---------------------------------------------------------------------------------------
+template <int N>
+CCAL_HD void gj_row_step(int j, bool mine, double d, double s, const double prow[N], double pb, double a[N], double &b,
+                         double &diag) {
+    const double dn = mine ? 1.0 : d * s;
+    const double f = mine ? 0.0 : -(a[j] * s);
+    diag = mine ? d : diag * dn;
+#pragma unroll
+    for (int k = 0; k < N; k++)
+        if (k > j) a[k] = fma(prow[k], f, a[k] * dn);
+    b = fma(pb, f, b * dn);
+}
+
+// ---------------------------------------------------------------------------------------
 // Julia-side maps (reference src/meta.jl), single radial coefficient k
 // ---------------------------------------------------------------------------------------
 // largest real root of c0 + x^2 - x^3 (src/meta.jl:50-57), closed form + Newton polish

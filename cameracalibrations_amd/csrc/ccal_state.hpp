@@ -4,12 +4,15 @@
 //   obj      [3,P]      f32   board template (shared by every image)
 //   img      [2,P,N]    f32   observed corners; the only O(N*P) stream: 8 B per corner-residual
 //   ext0     [N][8]     f64   initial rvec,tvec (+2 pad) per image (a solve can be re-run from it)
-//   blk      [2][N][72] f64   per-image state, double-buffered: parity p holds the last ACCEPTED
-//                             point ("prev"), 1-p the candidate being evaluated.  Per image (576 B):
+//   blk      [2][N][128] f64   per-image state, double-buffered: parity p holds the last ACCEPTED
+//                             point ("prev"), 1-p the candidate being evaluated.  Per image (1 KB):
 //                             rvec,tvec | U = C_l^-1 [B^T | h] for the lambda the next step uses
 //                             (back-substitution is then one 6x9 mat-vec) | pd flag
-//   partials [nblk][68] f64   per-workgroup partial sums of the reduced intrinsic system
-//   red      [68]       f64   the reduced system (what is all-reduced across GPUs)
+//   acc      [3][R][5][68] i64  the reduced intrinsic system of one trial, summed EXACTLY: every workgroup adds
+//                             its 68 partial sums as fixed-point limbs with integer atomics (order-independent,
+//                             hence bit-deterministic); R replicas spread the adds, three buffers rotate
+//                             (trial k adds into k % 3, reads (k - 1) % 3, clears (k + 1) % 3)
+//   red      [68]       f64   the reduced system as doubles (what is all-reduced across GPUs)
 //   LmState             the OpenCV CvLevMarq state machine, advanced on device
 #pragma once
 
@@ -26,12 +29,32 @@ constexpr int RED_DNUM = 64;   // sum ||ext_cand - ext_prev||^2
 constexpr int RED_DDEN = 65;   // sum ||ext_prev||^2
 constexpr int RED_BAD = 66;    // images with a non-PD block or non-finite error (67: pad)
 
-// per-image block (doubles): everything the next sweep's prologue needs sits in the first 72
-// doubles, so one coalesced 576-B read per parity fetches it
-constexpr int BLK = 72;        // per-image block stride
-constexpr int BLK_EXT = 0;     // rvec, tvec (6) + 2 pad
-constexpr int BLK_U = 8;       // U[j][k] = (C_l^-1 col_j)[k]: j = 0..8 columns of B^T, j = 9: h   (60)
-constexpr int BLK_PD = 68;     // 1.0 if the damped 6x6 block was positive definite (+3 pad)
+// ---- exact accumulation of the reduced system across workgroups ---------------------------------
+// A double is split into (at most two) signed 52-bit limbs of a 260-bit fixed-point number
+//     value = sum_j limb_j * 2^(52 j - 150),   |value| < 2^109,  resolution 2^-150
+// and added with 64-bit integer atomics: integer addition commutes, so the sum does not depend on
+// the order in which workgroups finish -- every rerun, every workgroup and every grid shape sees the
+// same bits, and the sum is exact (one rounding, when the limbs are turned back into a double).
+// Headroom: a limb holds 52 payload bits, so 2^11 adds per address cannot overflow an int64.
+constexpr int ACC_LIMBS = 5;
+constexpr int ACC_LIMB_BITS = 52;
+constexpr int ACC_LSB_EXP = -150;
+constexpr int ACC_ROW = ACC_LIMBS * NRED;   // int64 words per replica, layout [limb][column]
+constexpr int ACC_FLAG_COL = 67;            // pad column: limb 0 counts NaN contributions, limb 1 out-of-range ones
+constexpr int ACC_BUFS = 3;
+constexpr int ACC_MAX_REPLICAS = 64;
+constexpr int ACC_MAX_ADDS = 1500;          // adds per address and trial the host allows (2^11 would still be safe)
+
+// per-image block (doubles): two coalesced 512-byte reads per parity fetch everything the next sweep's
+// back-substitution needs, already laid out one value per lane so that the 6x10 mat-vec
+//     delta_i = u_h - U_B delta_int          U = C_l^-1 [B^T | h],  U[j][k]: j = 0..8 columns of B^T, j = 9: h
+// is one multiply and a 4-step DPP sum inside rows of 16 lanes (no LDS transposition):
+//   words   0..63   lane 16 k + j: U[j][k] for k = 0..3  (j = 0..9, lanes with j > 9 are zero)
+//   words  64..95   lane 16 (k - 4) + j: U[j][k] for k = 4, 5
+//   words  96..101  rvec, tvec;   word 102: 1.0 if the damped 6x6 block was positive definite;   rest zero
+constexpr int BLK = 128;       // per-image block stride
+constexpr int BLK_EXT = 96;    // rvec, tvec (6)
+constexpr int BLK_PD = 102;    // pd flag
 // A rejected step is re-damped by sweeping the accepted point again with the larger lambda
 // (MODE_RESCHUR): rejections are rare, and not keeping the raw 6x16 Gram rows per image
 // removes 768 B of writes per image from every sweep.

@@ -42,6 +42,21 @@ __device__ __forceinline__ double wave_sum(double v) {
     return t;
 }
 
+// Value of lane J of the same row of 16 lanes (row_newbcast: a plain VALU move, no SGPR round trip); J constant.
+template <int J>
+__device__ __forceinline__ double row_bcast16(double v) {
+    return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xF, 0xF, true);   // one v_mov_b64_dpp
+}
+
+// Sum inside each row of 16 lanes (lanes 16 r .. 16 r + 15), same value in every lane of the row.
+__device__ __forceinline__ double row_sum16(double v) {
+    v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);    // row_half_mirror
+    v += dpp_mov<0x140>(v);    // row_mirror
+    return v;
+}
+
 __device__ __forceinline__ double wave_max(double v) {
     v = fmax(v, dpp_mov<0xB1>(v));
     v = fmax(v, dpp_mov<0x4E>(v));

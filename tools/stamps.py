@@ -10,10 +10,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "cameracalibrations_amd", "csrc")
-OUT = "/tmp/libccal_hip_stamps.so"
+BLOCK = int(os.environ.get("CCAL_STAMP_BLOCK", "7"))
+OUT = "/tmp/libccal_hip_stamps_%d.so" % BLOCK
 srcs = [os.path.join(CSRC, f) for f in ("ccal_lm.hip", "ccal_init.hip", "ccal_maps.hip", "ccal_comm.hip", "ccal_p2p.hip", "ccal_detect.hip", "ccal_api.hip")]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
-                       "-DCCAL_STAMPS", "-o", OUT, *srcs, "-ldl"])
+                       "-DCCAL_STAMPS", "-DCCAL_STAMP_BLOCK=%d" % BLOCK, "-o", OUT, *srcs, "-ldl"])
 from cameracalibrations_amd import _ffi as F  # noqa: E402
 F.LIB_PATH = OUT
 from cameracalibrations_amd import synthetic as syn  # noqa: E402
@@ -22,8 +23,8 @@ from cameracalibrations_amd.solver import Solver  # noqa: E402
 L = F.lib()
 L.ccal_debug_stamps.restype = C.c_int
 wl = syn.named_workload("C3")
-names = ["entry", "state + reduce partials + advance", "head -> pose (backsubst)", "rotation R,K", "point_rows",
-         "tile store", "mfma gram", "Gram -> LDS", "chol6 + U + Y", "block store", "outputs + WG partial"]
+names = ["entry", "state + accumulators + advance", "head -> pose (backsubst)", "rotation R,K", "point_rows",
+         "tile store", "mfma gram", "Gram -> LDS", "chol6 + Y", "outputs + WG sum + atomics", "U + block store"]
 with Solver(0) as s:
     s.set_problem(wl.obj, wl.n_images, wl.image_size, aspect=wl.aspect, flags=wl.flags)
     s.set_image_points(wl.img)
@@ -37,8 +38,11 @@ with Solver(0) as s:
         print("total cycles", t[10] - t[0], "(%.2f us at 2.4 GHz)" % ((t[10] - t[0]) / 2400.0))
         for n, v in zip(names[1:], d):
             print(f"   {n:24s} {v:7d}")
+        rt = int(buf[31]) - int(buf[30])
+        if rt > 0:
+            print("   shader clock over this wave's lifetime: %.0f MHz (s_memtime / s_memrealtime x 100 MHz)" % (100.0 * (int(buf[10]) - int(buf[0])) / rt))
         t = np.array(buf[:13], dtype=np.int64)
-        print("   prologue: state load", t[11] - t[0], "reduce", t[12] - t[11], "advance+sync", t[1] - t[12])
+        print("   prologue: loads -> barrier", t[11] - t[0], "decode (+exchange)", t[12] - t[11], "advance+sync", t[1] - t[12])
         a = np.array(buf[16:20], dtype=np.int64)
         print("   advance: state machine", a[0] - t[12], "assemble S", a[1] - a[0], "chol9", a[2] - a[1], "solves", a[3] - a[2],
               "tail", t[1] - a[3])
