@@ -4,16 +4,20 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (config.workload): BASELINE.json configs[2] -- synthetic pinhole + k1,k2,p1,p2,
-1000 images x 9x6 corners per GPU (SURVEY.md 8d recipe, cameracalibrations_amd/synthetic.py),
-observed corners resident in HBM before the timed region.  With N GPUs every rank holds its
-own 1000-image shard of ONE joint fit (shared intrinsics): weak scaling, one RCCL all-reduce of
-the 68-double reduced system per LM trial.
+Headline workload (config.workload)
+  N = 1: BASELINE.json configs[2] -- synthetic pinhole + k1,k2,p1,p2, 1000 images x 9x6 corners on one MI355X.
+  N > 1: BASELINE.json configs[3] -- the SAME 1000-image set sharded per image over the N ranks (strong
+         scaling), one exchange of the 68-double reduced intrinsic system per LM trial.
+Extra blocks of the same JSON line (never `value`):
+  "weak_scaling"  N > 1: every rank holds its own 1000 images of one joint fit (1000 N images).
+  "c5"            BASELINE.json configs[4] shape, 10000 x 15x10 corners, full k1..k3,p1,p2 model: whole on the
+                  one GPU at N = 1, sharded 10000 / N images per rank at N > 1 (1250 per rank at 8).
+  "maps"          RowCol <-> XYZ maps and the four RMS error metrics on C3's 54 000 corners (N = 1).
 
-One step = one complete global LM solve from the closed-form initial
-values (rows A4/A5 run once on the device before timing and are reported separately, as
-SURVEY.md 8d defines the metric).  value = corner-residual evaluations (each with its
-2x(6+K) Jacobian block accumulated) per second over the whole job.
+One step = one complete global LM solve from the closed-form initial values (rows A4/A5
+run once on the device before timing and are reported separately, as SURVEY.md 8d defines the metric), observed
+corners resident in HBM before the timed region.  value = corner-residual evaluations (each with its 2x(6+K)
+Jacobian block accumulated into the normal equations) per second over the whole job.
 """
 import argparse
 import json
@@ -26,7 +30,38 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6    # FP64 vector (= FP64 matrix) peak: 256 CUs x 128 flop/clk x 2.4 GHz
+KERNEL_BOUNDARY_US = 1.45  # dependent kernel boundary, same stream (guide, "boundary" row of the price list)
+METRIC = "corner-residuals/sec + LM iters-to-tol, 1000 imgs x 9x6 corners, 1/2/4/8 GPU"
+
+MODEL_TEXT = {
+    "pinhole": "synthetic pinhole (fx,fy,cx,cy only, no distortion)",
+    "k1k2p1p2": "synthetic pinhole + k1,k2,p1,p2",
+    "full": "synthetic pinhole + k1,k2,k3,p1,p2 (full 5-coefficient model)",
+    "ref": "synthetic data under the reference's own flag word (f,cx,cy,k1; fixed aspect)",
+}
+
+
+def free_intrinsics(flags):
+    """K of SURVEY.md 8: free intrinsic parameters under an OpenCV flag word."""
+    from cameracalibrations_amd import synthetic as syn
+    free = [True] * 9                                   # fx fy cx cy k1 k2 p1 p2 k3
+    if flags & syn.FIX_ASPECT_RATIO:
+        free[0] = False
+    if flags & syn.FIX_FOCAL_LENGTH:
+        free[0] = free[1] = False
+    if flags & syn.FIX_PRINCIPAL_POINT:
+        free[2] = free[3] = False
+    if flags & (syn.ZERO_TANGENT_DIST | syn.FIX_TANGENT_DIST):
+        free[6] = free[7] = False
+    if flags & syn.FIX_K1:
+        free[4] = False
+    if flags & syn.FIX_K2:
+        free[5] = False
+    if flags & syn.FIX_K3:
+        free[8] = False
+    return sum(free)
 
 
 def algorithmic_bytes_per_sweep(N, P):
@@ -34,13 +69,14 @@ def algorithmic_bytes_per_sweep(N, P):
     return N * P * (8.0 + 96.0 / P)
 
 
-def pmc_traffic_bytes(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same
-    command (tools/pmc.sh: FETCH_SIZE and WRITE_SIZE in separate passes, both calibrated on a
-    known byte count with this code's access width).  None if the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_summary.json")
+def flops_per_corner_residual(K):
+    """projection + Jacobian ~250, symmetric JtJ rank-2 update, Jt e."""
+    return 250 + 2 * (6 + K) * (7 + K) + 4 * (6 + K)
+
+
+def committed_profile(name):
     try:
-        return float(json.load(open(path))[kernel]["hbm_bytes_per_launch"])
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:      # noqa: BLE001
         return None
 
@@ -63,7 +99,9 @@ def cpu_baseline(wl, criteria, budget_s=12.0):
         reps += 1
     out = {"value": units / t_lm, "unit": "corner-residuals/s", "cores": cores, "kind": "port",
            "sample": f"{reps} x full {wl.name} fit ({wl.n_images} x {wl.n_points}), criteria {criteria}, "
-                     f"oracle Schur mode, LM loop only; rms {r['rms']:.6f} px, iters {r['iters']}"}
+                     f"oracle Schur mode, LM loop only; rms {r['rms']:.6f} px, iters {r['iters']}",
+           "build": "oracle/ccal_oracle.c, " + getattr(orc, "BUILD_FLAGS", "gcc -O2 -ffp-contract=off -fopenmp (no -march=native)"),
+           "counts": "Jacobian sweeps + error-only sweeps, as OpenCV's loop makes them"}
     # the solve as OpenCV stores it (dense (18+6N)^2 normal equations, one thread) is cubic in N: a 250-image
     # sample of the same workload (the full 1000 images need minutes per fit)
     n = min(wl.n_images, 250)
@@ -83,7 +121,6 @@ def opencv_baseline(wl, criteria, budget_s=20.0):
     error), and the port above stays the only baseline."""
     try:
         import cv2
-        import numpy as np
         n = min(wl.n_images, 60)
         obj = [wl.obj.astype(np.float32)] * n
         img = [wl.img[i].astype(np.float32) for i in range(n)]
@@ -101,89 +138,121 @@ def opencv_baseline(wl, criteria, budget_s=20.0):
         return None
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="C3")
-    ap.add_argument("--images", type=int, default=None, help="override images per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--allreduce", default=os.environ.get("CCAL_ALLREDUCE", "p2p"), choices=["p2p", "rccl", "torch"],
-                    help="N > 1: 'p2p' = direct xGMI row exchange kernels (self-tested at start-up, else falls back), "
-                         "'rccl' = ncclAllReduce called by the library itself, 'torch' = torch.distributed hook")
-    ap.add_argument("--strong", action="store_true",
-                    help="N > 1: shard ONE problem of the named size over the ranks (BASELINE.json configs[3]) instead of "
-                         "giving every rank its own shard of that size; the JSON then says scaling = strong")
-    ap.add_argument("--timed-only", action="store_true",
-                    help="profiling runs: only the timed solves (skip the converged-criteria run, so that counter means "
-                         "are means over the timed region's launches)")
-    ap.add_argument("--share-gpu", action="store_true",
-                    help="rehearsal on a one-GPU box: all ranks use cuda:0 and rendezvous over gloo (not a measurement)")
-    args = ap.parse_args()
+def maps_block(wl, rf, with_cpu=True, reps=20):
+    """RowCol <-> XYZ maps and the four RMS metrics (reference src/meta.jl:82,88, src/buildcalibrations.jl:37-67) on the
+    headline workload's corners, through the same C ABI a Julia caller would use: host arrays in, host arrays out
+    (PCIe-inclusive by construction -- these entry points take caller-owned host buffers), one call for all images."""
+    from cameracalibrations_amd.solver import Solver
+    N, P = wl.n_images, wl.n_points
+    f, c, k = rf["intr"][:2].copy(), rf["intr"][2:4].copy(), float(rf["intr"][4])   # the Julia maps carry one radial coefficient
+    rv, tv = rf["rvecs"], rf["tvecs"]
+    obj = wl.obj.astype(np.float64)
+    img = wl.img.astype(np.float64)
+    rng = np.random.default_rng(0)
+    inv_pts = rng.random((N, 100, 2)) * (np.asarray(wl.image_size, dtype=np.float64) - 1) + 1     # inverse_samples = 100
+    out = {"points": N * P, "what": "one C-ABI call per quantity over all images, host buffers in and out (PCIe inclusive); camera = "
+                                    "this fit seen through the reference's single-k map model (k2, p1, p2, k3 dropped)"}
+    with Solver(0) as s:
+        def rate(fn, units):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+            return units * reps / (time.perf_counter() - t0), r
+        out["forward_points_per_s"], rc = rate(lambda: s.project_many(obj, f, c, k, rv, tv, 1.0), N * P)
+        out["inverse_points_per_s"], _ = rate(lambda: s.unproject_many(rc, f, c, k, rv, tv, 1.0), N * P)
+        out["errors_corners_per_s"], e = rate(lambda: s.errors(wl.n_corners, obj, img, f, c, k, rv, tv, 1.0, inv_pts=inv_pts), N * P)
+        out["errors"] = {kk: float(v) for kk, v in e.items()}
+        one = np.array([[1.0, 2.0, 0.0]])
+        t0 = time.perf_counter()
+        for _ in range(200):
+            s.project(one, f, c, k, rv[0], tv[0], 1.0)
+        out["single_point_call_us"] = 1e6 * (time.perf_counter() - t0) / 200
+    if with_cpu:
+        from oracle import oracle as orc
+        n = min(N, 200)
+        t0 = time.perf_counter()
+        for i in range(n):
+            orc.map_forward(obj, f, c, k, rv[i], tv[i], 1.0)
+        out["cpu_forward_points_per_s"] = n * P / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        for i in range(n):
+            orc.map_inverse(rc[i], f, c, k, rv[i], tv[i], 1.0)
+        out["cpu_inverse_points_per_s"] = n * P / (time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        eo = orc.errors(wl.n_corners, obj, img, f, c, k, rv, tv, 1.0, inv_pts=inv_pts)
+        out["cpu_errors_corners_per_s"] = N * P / (time.perf_counter() - t0)
+        out["cpu"] = f"oracle (plain C, one thread), {n} images for the maps, all {N} for the metrics"
+        out["errors_vs_cpu_max_abs"] = float(max(abs(eo[kk] - e[kk]) for kk in eo))
+    return out
 
-    import torch
-    import torch.distributed as dist
 
-    from cameracalibrations_amd import synthetic as syn
-    from cameracalibrations_amd.distributed import TorchAllReduce, allgather_bytes_via_torch, broadcast_id_via_torch
-    from cameracalibrations_amd.solver import CRITERIA, Solver
+class Job:
+    """One rank's side of the bench: process group, transports, timing helpers."""
 
-    world = args.gpus
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        assert int(os.environ.get("WORLD_SIZE", "1")) == world, "launch with torch.distributed.run --nproc-per-node N"
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.share_gpu:
-            local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.args = torch, dist, args
+        self.world = args.gpus
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world > 1:
+            assert int(os.environ.get("WORLD_SIZE", "1")) == self.world, "launch with torch.distributed.run --nproc-per-node N"
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.share_gpu:
+                self.local_rank = 0
+                torch.cuda.set_device(0)
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", self.local_rank))
         else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank)
-    cdev = "cpu" if (world > 1 and args.share_gpu) else dev          # where torch.distributed tensors live
+            torch.cuda.set_device(0)
+        self.dev = torch.device("cuda", self.local_rank)
+        self.cdev = "cpu" if (self.world > 1 and args.share_gpu) else self.dev   # where torch.distributed tensors live
 
-    # per-rank shard of the joint problem (different images on every rank, same camera)
-    strong = bool(args.strong and world > 1)
-    if strong:
-        from cameracalibrations_amd.distributed import shard_range
-        wl = syn.named_workload(args.workload, n_images=args.images)
-        lo, hi = shard_range(wl.n_images, world, rank)
-        n_total, my_img = wl.n_images, wl.img[lo:hi]
-    else:
-        wl = syn.named_workload(args.workload, n_images=args.images, seed_offset=1000 * rank)
-        n_total, my_img = wl.n_images * world, wl.img
-    N, P = my_img.shape[0], wl.n_points
-    img_dev = torch.from_numpy(np.ascontiguousarray(my_img)).to(dev)   # inputs resident in HBM
-    torch.cuda.synchronize()
-    # the context's own non-blocking stream (not torch's legacy default stream, which serialises with every
-    # blocking stream of the process): the timed region is bracketed by device-wide synchronisation anyway
-    s = Solver(local_rank)
-    s.set_problem(wl.obj, N, wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=CRITERIA[0], eps=CRITERIA[1])
-    s.set_image_points(img_dev)
+    # ---- collectives over the bench's own process group (never inside the timed data path) ----
+    def all_agree(self, ok):
+        if self.world == 1:
+            return bool(ok)
+        t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item())
 
-    def attach_comm(sol):
-        if world == 1:
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return float(x)
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+    # ---- transports: every stage is decided by ALL ranks together (a rank never changes transport alone) ----
+    def attach_comm(self, sol, n_total):
+        from cameracalibrations_amd.distributed import TorchAllReduce, allgather_bytes_via_torch, broadcast_id_via_torch
+        if self.world == 1:
             return "none"
-
-        def all_agree(ok):
-            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            return bool(t.item())
-
-        if args.allreduce == "p2p":
+        world, rank, want = self.world, self.rank, self.args.allreduce
+        if want == "p2p":
             why = ""
             try:
-                sol.init_p2p(world, rank, n_total, allgather_bytes_via_torch())
+                sol.init_p2p(world, rank, n_total, allgather_bytes_via_torch())   # (the all-gather inside is always joined)
                 ok = True
             except Exception as exc:      # noqa: BLE001
                 ok, why = False, str(exc)
-            if all_agree(ok):
-                dist.barrier()            # every inbox is mapped before the first row is sent
+            if self.all_agree(ok):
+                self.dist.barrier()       # every inbox is mapped before the first row is sent
                 try:
                     sol.p2p_selftest(16)
                     # ... and the real thing: init (8-double exchange) + two sharded solves (fused exchange, graph replay)
@@ -193,131 +262,311 @@ def main():
                     sol.lm_run()
                 except Exception as exc:  # noqa: BLE001
                     ok, why = False, str(exc)
-                if all_agree(ok):
+                if self.all_agree(ok):
                     return "p2p (direct xGMI row exchange kernels, self-tested)"
-            print(f"[bench] rank {rank}: direct exchange unavailable ({why or 'a peer failed'}); using RCCL", file=sys.stderr)
-        if args.allreduce in ("p2p", "rccl"):
+            print(f"[bench] rank {rank}: direct exchange unavailable ({why or 'a peer failed'}); all ranks use RCCL",
+                  file=sys.stderr)
+        if want in ("p2p", "rccl") and not self.args.share_gpu:   # (RCCL refuses two ranks on one device: rehearsals skip it)
+            # the broadcast of the id is collective: every rank joins it whether or not its own part worked
+            ok, why = True, ""
+            ident = None
             try:
-                sol.init_rccl(world, rank, n_total, broadcast_id_via_torch())
-                return "rccl (ncclAllReduce inside the library)"
-            except Exception as exc:      # noqa: BLE001 - fall back to the torch hook on every rank
-                print(f"[bench] rank {rank}: native RCCL unavailable ({exc}); using the torch hook", file=sys.stderr)
+                from cameracalibrations_amd import _ffi as F
+                import ctypes as C
+                buf = C.create_string_buffer(128)
+                if rank == 0:
+                    F.check(F.lib().ccal_comm_unique_id(buf))
+                ident = buf.raw
+            except Exception as exc:      # noqa: BLE001
+                ok, why = False, str(exc)
+            ident = broadcast_id_via_torch()(ident if (rank == 0 and ok) else (bytes(128) if rank == 0 else None))
+            ok = ok and ident != bytes(128)
+            if self.all_agree(ok):
+                try:
+                    sol.init_rccl(world, rank, n_total, lambda _b: ident)
+                except Exception as exc:  # noqa: BLE001
+                    ok, why = False, str(exc)
+                if self.all_agree(ok):
+                    return "rccl (ncclAllReduce inside the library)"
+            # decided by all ranks together: a rank whose own RCCL set-up worked drops it again (set_allreduce below)
+            print(f"[bench] rank {rank}: native RCCL unavailable ({why or 'a peer failed'}); all ranks use the torch hook",
+                  file=sys.stderr)
         sol.set_allreduce(TorchAllReduce(), world, rank, n_total)
         return "torch.distributed all_reduce hook"
 
-    comm_kind = attach_comm(s)
-    s.init_intrinsics()
-    s.init_extrinsics()
+    # ---- one workload: solver set-up, timed solves, launch timing ----
+    def make_solver(self, wl, my_img, n_total, criteria):
+        from cameracalibrations_amd.solver import Solver
+        img_dev = self.torch.from_numpy(np.ascontiguousarray(my_img)).to(self.dev)   # inputs resident in HBM
+        self.torch.cuda.synchronize()
+        # the context's own non-blocking stream (not torch's legacy default stream, which serialises with every
+        # blocking stream of the process): the timed region is bracketed by device-wide synchronisation anyway
+        s = Solver(self.local_rank)
+        s.set_problem(wl.obj, my_img.shape[0], wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=criteria[0],
+                      eps=criteria[1])
+        s.set_image_points(img_dev)
+        comm = self.attach_comm(s, n_total)
+        s.init_intrinsics()
+        s.init_extrinsics()
+        return s, img_dev, comm
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def timed_solves(self, s, steps, warmup):
+        for _ in range(warmup):
+            s.lm_run()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s.lm_run()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0), s.result()
 
-    for _ in range(args.warmup):
-        s.lm_run()
-    # --- timed region: exactly K steps -------------------------------------------------
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        s.lm_run()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    r = s.result()
-    sweeps = (r["sweeps"] + r["reschur"]) * args.steps   # deterministic: every step repeats the same solve
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def launch_timing(self, s, steps):
+        """mean device time of the sweeping k_lm_trial launches inside solves (HIP events bound to the dispatches on
+        the launch stream) and of back-to-back first-trial launches"""
+        s.set_sweep_timing(True)
+        us, n_timed, t1 = 0.0, 0, time.perf_counter()
+        for _ in range(steps):
+            s.lm_run()
+            rr = s.result()
+            us += rr["sweep_us"] * rr["timed_sweeps"]
+            n_timed += rr["timed_sweeps"]
+        self.torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        s.set_sweep_timing(False)
+        return us / max(n_timed, 1), n_timed, s.time_sweep(200), dt / max(steps, 1)
 
-    # --- sweep-kernel duration, HIP events on the launch stream, same steps re-run -------
-    s.set_sweep_timing(True)
-    us, n_timed, t1 = 0.0, 0, time.perf_counter()
-    for _ in range(args.steps):
-        s.lm_run()
-        rr = s.result()
-        us += rr["sweep_us"] * rr["timed_sweeps"]
-        n_timed += rr["timed_sweeps"]
-    torch.cuda.synchronize()
-    elapsed_events = time.perf_counter() - t1
-    s.set_sweep_timing(False)
-    sweep_us = us / max(n_timed, 1)
-    sweep_us_b2b = s.time_sweep(200)
 
-    # --- separately reported: closed-form init and a full fit ---------------------------
+def shard(wl, world, rank):
+    from cameracalibrations_amd.distributed import shard_range
+    lo, hi = shard_range(wl.n_images, world, rank)
+    return wl.img[lo:hi]
+
+
+def roofline_block(N_rank, P, K, sweep_us, n_timed, b2b_us, events_ms_per_step, kernel):
+    """the dominant kernel against its ceilings: HBM (the contract's classification), FP64 and the latency floor"""
+    alg_bytes = algorithmic_bytes_per_sweep(N_rank, P)
+    achieved = alg_bytes / (sweep_us * 1e-6) / 1e9 if sweep_us > 0 else 0.0
+    flops = N_rank * P * flops_per_corner_residual(K)
+    tflops = flops / (sweep_us * 1e-6) / 1e12 if sweep_us > 0 else 0.0
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "traffic": None, "traffic_source": None, "kernel": kernel,
+           "algorithmic_bytes_per_launch": alg_bytes,
+           # SURVEY.md 8d diagnostic: the same sweep with the per-image blocks kept in HBM (this design: one
+           # 1-KB block read for both parities and written once per image and sweep)
+           "bytes_per_launch_with_blocks_in_hbm": alg_bytes + N_rank * 3 * 1024,
+           "avg_launch_us": sweep_us, "launches_timed": n_timed, "avg_launch_us_back_to_back": b2b_us,
+           "timed_region_with_events_ms_per_step": events_ms_per_step,
+           "fp64_flop_per_launch": flops, "fp64_tflops": tflops, "fp64_peak_tflops": FP64_PEAK_TFLOPS,
+           "fp64_frac": tflops / FP64_PEAK_TFLOPS}
+    # traffic: HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/pmc.sh:
+    # FETCH_SIZE and WRITE_SIZE in separate passes, both calibrated on a known byte count with this access width)
+    pmc = committed_profile("r02_pmc_traffic_summary.json")
+    if pmc and (N_rank, P) == (1000, 54) and "ccal::k_lm_trial" in pmc:
+        out["traffic"] = float(pmc["ccal::k_lm_trial"]["hbm_bytes_per_launch"])
+        out["traffic_source"] = "committed profile profiles/r02_pmc_traffic_summary.json (not measured in this run)"
+    # latency floor (SURVEY.md 8d): with one wavefront per SIMD a launch cannot be shorter than a kernel boundary plus
+    # one wavefront's own dependent instruction stream; the stream length comes from the committed s_memtime stamps
+    st = committed_profile("r02_wave_stamps.json")
+    if st and (N_rank, P) == (st.get("N"), st.get("P")):
+        wave_us = st["wave_cycles"] / st["clock_mhz"]
+        out["latency_floor_us"] = KERNEL_BOUNDARY_US + wave_us
+        out["frac_of_floor"] = (KERNEL_BOUNDARY_US + wave_us) / sweep_us if sweep_us > 0 else None
+        out["latency_floor_source"] = (f"{KERNEL_BOUNDARY_US} us kernel boundary (guide) + one wavefront's instruction stream, "
+                                       f"{st['wave_cycles']} shader cycles at {st['clock_mhz']:.0f} MHz "
+                                       "(profiles/r02_wave_stamps.json, diagnostic build)")
+    else:
+        out["latency_floor_us"] = out["frac_of_floor"] = None
+    return out
+
+
+def lm_block(r, rt=None, tight_ms=None):
+    d = {"iters_to_tol_1e-3": r["iters"], "sweeps_per_solve": r["sweeps"], "redamping_sweeps_per_solve": r["reschur"],
+         "rejected": r["rejected"], "rms_px": r["rms"]}
+    if rt is not None:
+        d.update({"iters_to_tol_1e-10": rt["iters"], "sweeps_1e-10": rt["sweeps"], "redamping_sweeps_1e-10": rt["reschur"],
+                  "rejected_1e-10": rt["rejected"], "rms_px_1e-10": rt["rms"], "ms_per_solve_1e-10": tight_ms})
+    return d
+
+
+def config_block(wl, model, cfg_index, N_rank, n_total, world, comm, criteria, strong):
+    from cameracalibrations_amd import synthetic as syn  # noqa: F401
+    K = free_intrinsics(wl.flags)
+    if world == 1:
+        where = f"{n_total} images x {wl.n_corners[0]}x{wl.n_corners[1]} corners on 1 MI355X (BASELINE.json configs[{cfg_index}])"
+    elif strong:
+        where = (f"the same {n_total} images x {wl.n_corners[0]}x{wl.n_corners[1]} corners sharded per image over {world} "
+                 f"MI355X, {N_rank} on rank 0 (BASELINE.json configs[{cfg_index}])")
+    else:
+        where = (f"{N_rank} images x {wl.n_corners[0]}x{wl.n_corners[1]} corners per GPU, one joint fit of {n_total} images "
+                 f"over {world} MI355X (weak scaling of BASELINE.json configs[{cfg_index}])")
+    return {"workload": f"{wl.name}: {MODEL_TEXT.get(model, model)}, {where}",
+            "images_total": n_total, "images_rank0": N_rank, "corners_per_image": wl.n_points, "free_intrinsics": K,
+            "flags": wl.flags, "criteria": list(criteria), "step": "global LM solve (A6-A9) from device-side init",
+            "parallelism": f"image-sharded x{world}" if world > 1 else "single GPU", "allreduce": comm}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="C3", help="headline workload: C1, C3, C5, REF (cameracalibrations_amd/synthetic.py)")
+    ap.add_argument("--images", type=int, default=None, help="override the workload's image count")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the weak_scaling / c5 / maps blocks")
+    ap.add_argument("--allreduce", default=os.environ.get("CCAL_ALLREDUCE", "p2p"), choices=["p2p", "rccl", "torch"],
+                    help="N > 1: 'p2p' = direct xGMI row exchange kernels (self-tested at start-up, else every rank falls back "
+                         "together), 'rccl' = ncclAllReduce called by the library itself, 'torch' = torch.distributed hook")
+    ap.add_argument("--weak", action="store_true",
+                    help="N > 1: make the weak-scaling joint fit (every rank its own shard of the named size) the headline "
+                         "instead of BASELINE.json configs[3]; the JSON then says scaling = weak")
+    ap.add_argument("--strong", action="store_true", help="(default at N > 1; kept for older command lines)")
+    ap.add_argument("--timed-only", action="store_true",
+                    help="profiling runs: only the timed solves of the headline (no converged-criteria run, no extras), so "
+                         "that counter means are means over the timed region's launches")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: all ranks use cuda:0 and rendezvous over gloo (not a measurement)")
+    args = ap.parse_args()
+
+    from cameracalibrations_amd import synthetic as syn
+    from cameracalibrations_amd.solver import CRITERIA
+
+    job = Job(args)
+    world, rank = job.world, job.rank
+    strong = world > 1 and not args.weak
+    model = syn.CONFIGS[args.workload][2]
+    cfg_index = syn.CONFIGS[args.workload][3] if world == 1 else (3 if args.workload in ("C2", "C3") and strong else syn.CONFIGS[args.workload][3])
+    if args.workload == "C5":
+        cfg_index = 4
+
+    # ---- headline ---------------------------------------------------------------------------------------
+    if strong or world == 1:
+        wl = syn.named_workload(args.workload, n_images=args.images)
+        my_img = shard(wl, world, rank)
+        n_total = wl.n_images
+    else:      # weak scaling: a different shard of the same camera on every rank
+        wl = syn.named_workload(args.workload, n_images=args.images, seed_offset=1000 * rank)
+        my_img, n_total = wl.img, wl.n_images * world
+    N, P = my_img.shape[0], wl.n_points
+    K = free_intrinsics(wl.flags)
+    s, img_dev, comm_kind = job.make_solver(wl, my_img, n_total, CRITERIA)
+    elapsed, r = job.timed_solves(s, args.steps, args.warmup)
+    # like for like with OpenCV's loop (and the CPU baseline): sweeps at new candidate points count; the re-damping
+    # sweeps a rejected step costs THIS design are not counted as work, only their time is
+    sweeps = r["sweeps"] * args.steps
+    sweep_us, n_timed, sweep_us_b2b, ev_s = job.launch_timing(s, args.steps)
+
+    # closed-form init and a full fit, reported separately
     t2 = time.perf_counter()
     s.init_intrinsics()
     s.init_extrinsics()
     s.lm_run()
-    torch.cuda.synchronize()
+    job.torch.cuda.synchronize()
     fit_ms = 1e3 * (time.perf_counter() - t2)
     rf = s.result()
 
-    # --- converged criteria (100, 1e-10): iters-to-tol -----------------------------------
-    if args.timed_only:
-        rt, tight_ms = dict(iters=None, sweeps=0, reschur=0, rms=None), None
-    else:
+    # converged criteria (100, 1e-10): iters-to-tol
+    rt, tight_ms = None, None
+    if not args.timed_only:
         s.set_problem(wl.obj, N, wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=100, eps=1e-10)
         s.set_image_points(img_dev)
         s.init_intrinsics()
         s.init_extrinsics()
         s.lm_run()
-        torch.cuda.synchronize()
+        job.torch.cuda.synchronize()
         t3 = time.perf_counter()
         for _ in range(10):
             s.lm_run()
-        torch.cuda.synchronize()
+        job.torch.cuda.synchronize()
         tight_ms = 1e2 * (time.perf_counter() - t3)
         rt = s.result()
+    job.barrier()
 
+    out = None
     if rank == 0:
-        units = float(n_total) * P * sweeps
-        alg_bytes = algorithmic_bytes_per_sweep(N, P)
-        achieved = alg_bytes / (sweep_us * 1e-6) / 1e9 if sweep_us > 0 else 0.0
         out = {
-            "metric": "corner-residuals/sec + LM iters-to-tol, 1000 imgs x 9x6 corners, 1/2/4/8 GPU",
-            "value": units / elapsed,
+            "metric": METRIC,
+            "value": float(n_total) * P * sweeps / elapsed,
             "unit": "corner-residuals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "strong" if strong else "weak",
+            # the 1/2/4/8-GPU series is ONE 1000-image problem (configs[2] on one GPU, configs[3] sharded): total work fixed
+            "scaling": "strong" if (strong or world == 1) else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic" if not args.share_gpu else "synthetic (REHEARSAL: all ranks share one GPU, not a measurement)",
-            "config": {"workload": f"{wl.name}: synthetic pinhole + k1,k2,p1,p2, {N} images x "
-                                   f"{wl.n_corners[0]}x{wl.n_corners[1]} corners per GPU (BASELINE.json configs[2]), "
-                                   f"one joint fit over {world} GPU(s)",
-                       "images_per_gpu": N, "corners_per_image": P, "free_intrinsics": 8, "flags": wl.flags,
-                       "criteria": list(CRITERIA), "step": "global LM solve (A6-A9) from device-side init",
-                       "parallelism": f"image-sharded x{world}" if world > 1 else "single GPU",
-                       "allreduce": comm_kind},
-            "lm": {"iters_to_tol_1e-3": r["iters"], "sweeps_per_solve": r["sweeps"] + r["reschur"], "rejected": r["rejected"],
-                   "rms_px": r["rms"], "iters_to_tol_1e-10": rt["iters"], "sweeps_1e-10": rt["sweeps"] + rt["reschur"],
-                   "rms_px_1e-10": rt["rms"], "ms_per_solve_1e-10": tight_ms},
-            "init": {"intrinsics_ms": 1e3 * rf["t_init_intr_s"], "extrinsics_ms": 1e3 * rf["t_init_extr_s"],
-                     "full_fit_ms": fit_ms},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic_bytes("ccal::k_lm_trial") if (N, P) == (1000, 54) else None,
-                         "kernel": "ccal::k_lm_trial<false>", "algorithmic_bytes_per_launch": alg_bytes,
-                         # SURVEY.md 8d diagnostic: the same sweep with the per-image blocks kept in HBM (this design)
-                         "bytes_per_launch_with_blocks_in_hbm": alg_bytes + N * 2 * 8 * (27 + 6 * 8) if P == 54 else None,
-                         "avg_launch_us": sweep_us, "launches_timed": n_timed,
-                         "avg_launch_us_back_to_back": sweep_us_b2b,
-                         "timed_region_with_events_ms_per_step": 1e3 * elapsed_events / args.steps},
+            "config": config_block(wl, model, cfg_index, N, n_total, world, comm_kind, CRITERIA, strong),
+            "lm": lm_block(r, rt, tight_ms),
+            "init": {"intrinsics_ms": 1e3 * rf["t_init_intr_s"], "extrinsics_ms": 1e3 * rf["t_init_extr_s"], "full_fit_ms": fit_ms},
+            "roofline": roofline_block(N, P, K, sweep_us, n_timed, sweep_us_b2b, 1e3 * ev_s,
+                                       "ccal::k_lm_trial<true>" if world > 1 else "ccal::k_lm_trial<false>"),
+            "parity": "device == oracle (CPU restatement of OpenCV 4.10 from the published algorithm) in tests/; no run of OpenCV "
+                      "pins the trajectory (iters-to-tol) -- DESIGN.md section 2",
         }
+    s.close()
+    del s, img_dev
+
+    # ---- extra blocks (never `value`) ---------------------------------------------------------------------
+    extras = not (args.no_extras or args.timed_only)
+    # A rehearsal (--share-gpu) puts every rank's kernels on ONE GPU, and they wait for each other's rows: all ranks'
+    # workgroups must be resident together (256 CUs, one or two of these workgroups each), so the extra blocks are kept
+    # to 256 workgroups in total there.  A real run has one GPU per rank and uses the named sizes.
+    rehearsal_cap = 4 * (256 // world) if (args.share_gpu and world > 1) else 0
+    steps_x, warm_x = max(5, min(args.steps, 50)), 5
+    if extras and world > 1 and strong and args.workload in ("C2", "C3"):
+        try:
+            wlw = syn.named_workload(args.workload, n_images=(min(args.images or 1000, rehearsal_cap) if rehearsal_cap else args.images),
+                                     seed_offset=1000 * rank)
+            sw, _, comm_w = job.make_solver(wlw, wlw.img, wlw.n_images * world, CRITERIA)
+            el, rw = job.timed_solves(sw, steps_x, warm_x)
+            if rank == 0:
+                out["weak_scaling"] = {"value": float(wlw.n_images * world) * wlw.n_points * rw["sweeps"] * steps_x / el,
+                                       "unit": "corner-residuals/s", "ms_per_step": 1e3 * el / steps_x, "steps": steps_x,
+                                       "config": config_block(wlw, model, 2, wlw.n_images, wlw.n_images * world, world, comm_w,
+                                                              CRITERIA, False),
+                                       "lm": lm_block(rw)}
+            sw.close()
+            del sw
+        except Exception as exc:      # noqa: BLE001
+            if rank == 0:
+                out["weak_scaling"] = {"error": str(exc)}
+    if extras and args.workload != "C5":
+        try:
+            wl5 = syn.named_workload("C5", n_images=(rehearsal_cap * world if rehearsal_cap else None))
+            my5 = shard(wl5, world, rank)
+            s5, _, comm5 = job.make_solver(wl5, my5, wl5.n_images, CRITERIA)
+            st5 = max(5, min(args.steps, 20))
+            el, r5 = job.timed_solves(s5, st5, 3)
+            us5, n5, b2b5, ev5 = job.launch_timing(s5, min(st5, 10))
+            if rank == 0:
+                out["c5"] = {"value": float(wl5.n_images) * wl5.n_points * r5["sweeps"] * st5 / el, "unit": "corner-residuals/s",
+                             "ms_per_step": 1e3 * el / st5, "steps": st5,
+                             "config": config_block(wl5, "full", 4, my5.shape[0], wl5.n_images, world, comm5, CRITERIA, True),
+                             "lm": lm_block(r5),
+                             "roofline": roofline_block(my5.shape[0], wl5.n_points, free_intrinsics(wl5.flags), us5, n5, b2b5,
+                                                        1e3 * ev5, "ccal::k_lm_trial")}
+            s5.close()
+            del s5
+        except Exception as exc:      # noqa: BLE001
+            if rank == 0:
+                out["c5"] = {"error": str(exc)}
+    if extras and world == 1:
+        try:
+            out["maps"] = maps_block(wl, rf, with_cpu=not args.no_cpu_baseline)
+        except Exception as exc:      # noqa: BLE001
+            out["maps"] = {"error": str(exc)}
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl, CRITERIA)
             ocv = opencv_baseline(wl, CRITERIA)
             if ocv is not None:
                 out["cpu_baseline"]["opencv"] = ocv
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    job.close()
 
 
 if __name__ == "__main__":

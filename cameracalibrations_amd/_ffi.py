@@ -91,6 +91,8 @@ SIGNATURES = {
     "ccal_thread_cleanup": (None, []),
     "ccal_project": (C.c_int, [C.c_void_p, _dp, C.c_int32, _dp, _dp, C.c_double, _dp, _dp, C.c_double, _dp]),
     "ccal_unproject": (C.c_int, [C.c_void_p, _dp, C.c_int32, _dp, _dp, C.c_double, _dp, _dp, C.c_double, _dp]),
+    "ccal_project_many": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, C.c_double, _dp, _dp, C.c_double, _dp]),
+    "ccal_unproject_many": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32, _dp, _dp, C.c_double, _dp, _dp, C.c_double, _dp]),
     "ccal_errors": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _dp, _dp, _dp, _dp, C.c_double, _dp, _dp,
                               C.c_double, C.c_int32, _dp, _dp]),
     "ccal_rectify_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int64,

@@ -75,6 +75,10 @@ struct ccal_ctx {
     LmState *d_st = nullptr, *d_st_scratch = nullptr;
     TraceRec *d_trace = nullptr;
     int max_trace = 4096;
+    // grow-only device scratch + pinned, device-mapped staging of the map / metric / warp entry points
+    void *d_scratch = nullptr, *h_pin = nullptr;
+    size_t scratch_cap = 0;
+    std::vector<double> h_rt_stage;
     // pinned host mirrors
     LmState *h_st = nullptr;
     int *h_flags = nullptr;
@@ -173,6 +177,7 @@ int ccal_create(int device, ccal_ctx **out) {
     HIPCHK(hipMalloc(&c->d_intr0, sizeof(double) * 9));
     HIPCHK(hipMalloc(&c->d_intr_scratch, sizeof(double) * 9));
     HIPCHK(hipMalloc(&c->d_trace, sizeof(TraceRec) * c->max_trace));
+    HIPCHK(hipHostMalloc(&c->h_pin, 64 * 1024, hipHostMallocMapped));
     HIPCHK(hipHostMalloc(&c->h_st, sizeof(LmState), hipHostMallocDefault));
     HIPCHK(hipHostMalloc(&c->h_flags, sizeof(int) * 64, hipHostMallocDefault));   // flags | intr staging | progress
     const char *b = getenv("CCAL_LM_BATCH");
@@ -194,7 +199,7 @@ void ccal_destroy(ccal_ctx *c) {
     (void)hipFree(c->d_acc); (void)hipFree(c->d_acc_scratch);
     (void)hipFree(c->d_trace); (void)hipFree(c->d_intr0); (void)hipFree(c->d_intr_scratch);
     if (c->g_first) (void)hipGraphExecDestroy(c->g_first);
-    (void)hipHostFree(c->h_st); (void)hipHostFree(c->h_flags);
+    (void)hipHostFree(c->h_st); (void)hipHostFree(c->h_flags); (void)hipHostFree(c->h_pin); (void)hipFree(c->d_scratch);
     for (auto &e : c->ev) (void)hipEventDestroy(e);
     delete c->comm;
     delete c->p2p;
@@ -404,6 +409,9 @@ int ccal_set_image_points_device(ccal_ctx *c, const float *img_device) {
         (void)hipGetLastError();
         return fail(CCAL_E_ARG, "ccal_set_image_points_device: not a device pointer");
     }
+    if (attr.device != c->device)
+        return fail(CCAL_E_ARG, "ccal_set_image_points_device: the pointer lives on device " + std::to_string(attr.device) +
+                                    ", the context on device " + std::to_string(c->device));
     c->d_img = img_device;
     c->have_img = true;
     c->have_result = false;
@@ -1039,42 +1047,86 @@ int ccal_calibrate_multi(const float *obj, const float *img, int32_t P, int32_t 
 }
 
 // ---- point maps and error metrics (A11-A13) ---------------------------------------------
-namespace {
-struct DevBuf {                       // scratch device allocation, freed on scope exit
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-};
-}  // namespace
+// Device scratch of these entry points lives in the context and only ever grows: no hipMalloc / hipFree per
+// call.  Small calls (the reference's `c(rc, i)` for one point, src/meta.jl:82,88) do not even copy: input,
+// poses and output sit in one pinned, device-mapped staging block that the kernel reads and writes over PCIe,
+// so such a call is a memcpy, one launch and one stream synchronisation.
+static constexpr size_t PIN_BYTES = 64 * 1024;
 
-static int map_common(ccal_ctx *c, const double *in, int32_t M, int in_w, int out_w, const double f[2],
-                      const double cc[2], double k, const double rvec[3], const double tvec[3], double cs,
-                      double *out, bool forward) {
-    if (!c || !in || !out || !f || !cc || !rvec || !tvec) return fail(CCAL_E_ARG, "ccal map: NULL argument");
-    if (M < 0 || !(cs != 0.0)) return fail(CCAL_E_ARG, "ccal map: bad size / checker_size");
+static int scratch_need(ccal_ctx *c, size_t bytes) {
+    if (bytes <= c->scratch_cap) return CCAL_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    (void)hipFree(c->d_scratch);
+    c->d_scratch = nullptr;
+    c->scratch_cap = 0;
+    const size_t cap = bytes + bytes / 2 + 4096;
+    HIPCHK(hipMalloc(&c->d_scratch, cap));
+    c->scratch_cap = cap;
+    return CCAL_OK;
+}
+
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// in [in_w, M, N] (or one [3, M] template when !per_image) -> out [out_w, M, N], image n through pose n
+static int map_many(ccal_ctx *c, const double *in, int32_t M, int32_t N, bool per_image, const double f[2], const double cc[2],
+                    double k, const double *rvecs, const double *tvecs, double cs, double *out, bool forward) {
+    if (!c || !in || !out || !f || !cc || !rvecs || !tvecs) return fail(CCAL_E_ARG, "ccal map: NULL argument");
+    if (M < 0 || N < 1 || !(cs != 0.0)) return fail(CCAL_E_ARG, "ccal map: bad size / checker_size");
     if (M == 0) return CCAL_OK;
     HIPCHK(hipSetDevice(c->device));
-    DevBuf din, dout, dpar;
-    HIPCHK(hipMalloc(&din.p, sizeof(double) * in_w * (size_t)M));
-    HIPCHK(hipMalloc(&dout.p, sizeof(double) * out_w * (size_t)M));
-    HIPCHK(hipMalloc(&dpar.p, sizeof(double) * 12));
-    const double par[12] = {f[0], f[1], cc[0], cc[1], k, rvec[0], rvec[1], rvec[2], tvec[0], tvec[1], tvec[2], cs};
-    HIPCHK(hipMemcpyAsync(din.p, in, sizeof(double) * in_w * (size_t)M, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dpar.p, par, sizeof par, hipMemcpyHostToDevice, c->stream));
-    if (forward) HIPCHK(launch_map_forward(c->stream, (const double *)din.p, (double *)dout.p, M, (const double *)dpar.p));
-    else HIPCHK(launch_map_inverse(c->stream, (const double *)din.p, (double *)dout.p, M, (const double *)dpar.p));
-    HIPCHK(hipMemcpyAsync(out, dout.p, sizeof(double) * out_w * (size_t)M, hipMemcpyDeviceToHost, c->stream));
+    const int in_w = forward ? 3 : 2, out_w = forward ? 2 : 3;
+    const size_t n_in = (size_t)in_w * M * (per_image ? N : 1), n_out = (size_t)out_w * M * N, n_rt = (size_t)6 * N;
+    const size_t b_rt = align256(8 * n_rt), b_in = align256(8 * n_in), b_out = align256(8 * n_out);
+    MapIntr mi;
+    mi.f[0] = f[0]; mi.f[1] = f[1]; mi.c[0] = cc[0]; mi.c[1] = cc[1]; mi.k = k; mi.cs = cs;
+    const bool small = b_rt + b_in + b_out <= PIN_BYTES;
+    char *base;
+    if (small) {
+        base = static_cast<char *>(c->h_pin);
+    } else {
+        const int rc = scratch_need(c, b_rt + b_in + b_out);
+        if (rc) return rc;
+        base = static_cast<char *>(c->d_scratch);
+    }
+    double *d_rt = reinterpret_cast<double *>(base), *d_in = reinterpret_cast<double *>(base + b_rt),
+           *d_out = reinterpret_cast<double *>(base + b_rt + b_in);
+    // poses: [3,N] + [3,N] -> [6,N]
+    double *h_rt = small ? d_rt : (c->h_rt_stage.resize(n_rt), c->h_rt_stage.data());
+    for (int i = 0; i < N; i++)
+        for (int a = 0; a < 3; a++) { h_rt[(size_t)6 * i + a] = rvecs[(size_t)3 * i + a]; h_rt[(size_t)6 * i + 3 + a] = tvecs[(size_t)3 * i + a]; }
+    if (small) {
+        memcpy(d_in, in, 8 * n_in);
+    } else {
+        HIPCHK(hipMemcpyAsync(d_rt, h_rt, 8 * n_rt, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(d_in, in, 8 * n_in, hipMemcpyHostToDevice, c->stream));
+    }
+    if (forward) HIPCHK(launch_map_forward(c->stream, d_in, per_image ? (long long)3 * M : 0ll, d_out, M, N, mi, d_rt));
+    else HIPCHK(launch_map_inverse(c->stream, d_in, d_out, M, N, mi, d_rt));
+    if (!small) HIPCHK(hipMemcpyAsync(out, d_out, 8 * n_out, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (small) memcpy(out, d_out, 8 * n_out);
     return CCAL_OK;
 }
 
 int ccal_project(ccal_ctx *c, const double *xyz, int32_t M, const double f[2], const double cc[2], double k,
                  const double rvec[3], const double tvec[3], double checker_size, double *rowcol) {
-    return map_common(c, xyz, M, 3, 2, f, cc, k, rvec, tvec, checker_size, rowcol, true);
+    return map_many(c, xyz, M, 1, true, f, cc, k, rvec, tvec, checker_size, rowcol, true);
 }
 
 int ccal_unproject(ccal_ctx *c, const double *rowcol, int32_t M, const double f[2], const double cc[2], double k,
                    const double rvec[3], const double tvec[3], double checker_size, double *xyz) {
-    return map_common(c, rowcol, M, 2, 3, f, cc, k, rvec, tvec, checker_size, xyz, false);
+    return map_many(c, rowcol, M, 1, true, f, cc, k, rvec, tvec, checker_size, xyz, false);
+}
+
+int ccal_project_many(ccal_ctx *c, const double *xyz, int32_t M, int32_t N, int32_t per_image, const double f[2],
+                      const double cc[2], double k, const double *rvecs, const double *tvecs, double checker_size,
+                      double *rowcol) {
+    return map_many(c, xyz, M, N, per_image != 0, f, cc, k, rvecs, tvecs, checker_size, rowcol, true);
+}
+
+int ccal_unproject_many(ccal_ctx *c, const double *rowcol, int32_t M, int32_t N, const double f[2], const double cc[2],
+                        double k, const double *rvecs, const double *tvecs, double checker_size, double *xyz) {
+    return map_many(c, rowcol, M, N, true, f, cc, k, rvecs, tvecs, checker_size, xyz, false);
 }
 
 int ccal_errors(ccal_ctx *c, int32_t N, int32_t n1, int32_t n2, const double *obj_scaled, const double *img,
@@ -1086,35 +1138,34 @@ int ccal_errors(ccal_ctx *c, int32_t N, int32_t n1, int32_t n2, const double *ob
     const int P = n1 * n2;
     if ((size_t)P * 24 > 60000) return fail(CCAL_E_ARG, "ccal_errors: board too large for the per-image LDS tile");
     HIPCHK(hipSetDevice(c->device));
-    DevBuf dobj, dimg, dpar, drt, dinv, dpart;
-    HIPCHK(hipMalloc(&dobj.p, sizeof(double) * 3 * P));
-    HIPCHK(hipMalloc(&dimg.p, sizeof(double) * 2 * (size_t)P * N));
-    HIPCHK(hipMalloc(&dpar.p, sizeof(double) * 8));
-    HIPCHK(hipMalloc(&drt.p, sizeof(double) * 6 * (size_t)N));
-    HIPCHK(hipMalloc(&dpart.p, sizeof(double) * 4 * ((size_t)N + 1)));
-    std::vector<double> rt((size_t)6 * N);
+    const bool inv = S > 0 && inv_pts;
+    const size_t b_obj = align256(8 * (size_t)3 * P), b_img = align256(8 * (size_t)2 * P * N), b_rt = align256(8 * (size_t)6 * N),
+                 b_inv = inv ? align256(8 * (size_t)2 * S * N) : 0, b_part = align256(8 * (size_t)4 * (N + 1));
+    int rc = scratch_need(c, b_obj + b_img + b_rt + b_inv + b_part);
+    if (rc) return rc;
+    char *base = static_cast<char *>(c->d_scratch);
+    double *d_obj = reinterpret_cast<double *>(base), *d_img = reinterpret_cast<double *>(base + b_obj),
+           *d_rt = reinterpret_cast<double *>(base + b_obj + b_img), *d_inv = reinterpret_cast<double *>(base + b_obj + b_img + b_rt),
+           *d_part = reinterpret_cast<double *>(base + b_obj + b_img + b_rt + b_inv);
+    c->h_rt_stage.resize((size_t)6 * N);
     for (int i = 0; i < N; i++)
-        for (int a = 0; a < 3; a++) { rt[(size_t)6 * i + a] = rvecs[(size_t)3 * i + a]; rt[(size_t)6 * i + 3 + a] = tvecs[(size_t)3 * i + a]; }
-    const double par[8] = {f[0], f[1], cc[0], cc[1], k, checker_size, 0, 0};
-    HIPCHK(hipMemcpyAsync(dobj.p, obj_scaled, sizeof(double) * 3 * P, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dimg.p, img, sizeof(double) * 2 * (size_t)P * N, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dpar.p, par, sizeof par, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(drt.p, rt.data(), sizeof(double) * rt.size(), hipMemcpyHostToDevice, c->stream));
-    if (S > 0 && inv_pts) {
-        HIPCHK(hipMalloc(&dinv.p, sizeof(double) * 2 * (size_t)S * N));
-        HIPCHK(hipMemcpyAsync(dinv.p, inv_pts, sizeof(double) * 2 * (size_t)S * N, hipMemcpyHostToDevice, c->stream));
-    }
-    HIPCHK(launch_errors(c->stream, (const double *)dobj.p, (const double *)dimg.p, (const double *)dpar.p,
-                         (const double *)drt.p, (const double *)dinv.p, (double *)dpart.p, N, n1, n2, S));
-    double sums[4];
-    HIPCHK(hipMemcpyAsync(sums, (double *)dpart.p + (size_t)4 * N, sizeof sums, hipMemcpyDeviceToHost, c->stream));
+        for (int a = 0; a < 3; a++) { c->h_rt_stage[(size_t)6 * i + a] = rvecs[(size_t)3 * i + a]; c->h_rt_stage[(size_t)6 * i + 3 + a] = tvecs[(size_t)3 * i + a]; }
+    MapIntr mi;
+    mi.f[0] = f[0]; mi.f[1] = f[1]; mi.c[0] = cc[0]; mi.c[1] = cc[1]; mi.k = k; mi.cs = checker_size;
+    HIPCHK(hipMemcpyAsync(d_obj, obj_scaled, sizeof(double) * 3 * P, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_img, img, sizeof(double) * 2 * (size_t)P * N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(d_rt, c->h_rt_stage.data(), sizeof(double) * 6 * (size_t)N, hipMemcpyHostToDevice, c->stream));
+    if (inv) HIPCHK(hipMemcpyAsync(d_inv, inv_pts, sizeof(double) * 2 * (size_t)S * N, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_errors(c->stream, d_obj, d_img, mi, d_rt, inv ? d_inv : nullptr, d_part, N, n1, n2, S));
+    double *sums = static_cast<double *>(c->h_pin);     // pinned: the copy is a plain DMA, no staging
+    HIPCHK(hipMemcpyAsync(sums, d_part + (size_t)4 * N, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     // normalisation of src/buildcalibrations.jl:60-65
     const double n = (double)P * N;
     out[0] = std::sqrt(sums[0] / n);
     out[1] = std::sqrt(sums[1] / n);
     out[2] = std::sqrt(sums[2] / ((double)(n1 - 1) * (n2 - 1)) / N);
-    out[3] = (S > 0 && inv_pts) ? std::sqrt(sums[3] / S / N) : 0.0;
+    out[3] = inv ? std::sqrt(sums[3] / S / N) : 0.0;
     return CCAL_OK;
 }
 
@@ -1130,17 +1181,15 @@ int ccal_rectify_image(ccal_ctx *c, const uint8_t *img, int32_t rows, int32_t co
     HIPCHK(hipSetDevice(c->device));
     const size_t span = (size_t)((rows - 1) * stride_row + (cols - 1) * stride_col + (channels - 1) * stride_ch + 1);
     const size_t out_bytes = (size_t)out_rows * out_cols * channels;
-    DevBuf din, dout, dpar;
-    HIPCHK(hipMalloc(&din.p, span));
-    HIPCHK(hipMalloc(&dout.p, out_bytes));
-    HIPCHK(hipMalloc(&dpar.p, sizeof(double) * 16));
-    const double par[16] = {f[0], f[1], cc[0], cc[1], k, rvec[0], rvec[1], rvec[2], tvec[0], tvec[1], tvec[2],
-                            checker_size, ratio, index_offset, 0, 0};
-    HIPCHK(hipMemcpyAsync(din.p, img, span, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(dpar.p, par, sizeof par, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(launch_rectify(c->stream, (const uint8_t *)din.p, rows, cols, channels, stride_row, stride_col, stride_ch, a0, b0,
-                          out_rows, out_cols, (const double *)dpar.p, (uint8_t *)dout.p));
-    HIPCHK(hipMemcpyAsync(out, dout.p, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    const int rc = scratch_need(c, align256(span) + align256(out_bytes));
+    if (rc) return rc;
+    uint8_t *d_in = static_cast<uint8_t *>(c->d_scratch), *d_out = d_in + align256(span);
+    const RectPar par = {{f[0], f[1], cc[0], cc[1], k, rvec[0], rvec[1], rvec[2], tvec[0], tvec[1], tvec[2],
+                          checker_size, ratio, index_offset, 0, 0}};
+    HIPCHK(hipMemcpyAsync(d_in, img, span, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_rectify(c->stream, d_in, rows, cols, channels, stride_row, stride_col, stride_ch, a0, b0, out_rows, out_cols,
+                          par, d_out));
+    HIPCHK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return CCAL_OK;
 }

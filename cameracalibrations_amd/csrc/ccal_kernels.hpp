@@ -49,11 +49,16 @@ hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const fl
                                   double *ext, int *fail_count, int N, int P);
 
 // ccal_maps.hip -- RowCol <-> XYZ maps and the four RMS metrics
-hipError_t launch_map_forward(hipStream_t stream, const double *xyz, double *rc, int M, const double *par);
-hipError_t launch_map_inverse(hipStream_t stream, const double *rc, double *xyz, int M, const double *par);
+struct MapIntr { double f[2], c[2], k, cs; };   // intrinsic map parameters + checker_size, a kernel argument by value
+// [3, M, N] -> [2, M, N] (xyz_stride = 3 M) or one [3, M] template through N poses (xyz_stride = 0); rt [6, N]
+hipError_t launch_map_forward(hipStream_t stream, const double *xyz, long long xyz_stride, double *rc, int M, int N,
+                              const MapIntr &in, const double *rt);
+hipError_t launch_map_inverse(hipStream_t stream, const double *rc, double *xyz, int M, int N, const MapIntr &in,
+                              const double *rt);
+struct RectPar { double v[16]; };   // f0 f1 c0 c1 k rvec(3) tvec(3) checker_size ratio index_offset, by value
 hipError_t launch_rectify(hipStream_t stream, const uint8_t *img, int rows, int cols, int ch, long long sr, long long sc,
-                          long long sk, int a0, int b0, int out_rows, int out_cols, const double *par, uint8_t *out);
-hipError_t launch_errors(hipStream_t stream, const double *obj, const double *img, const double *par,
+                          long long sk, int a0, int b0, int out_rows, int out_cols, const RectPar &par, uint8_t *out);
+hipError_t launch_errors(hipStream_t stream, const double *obj, const double *img, const MapIntr &in,
                          const double *rt, const double *inv_pts, double *partials, int N, int n1, int n2, int S);
 
 }  // namespace ccal

@@ -588,10 +588,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
             // progress word (trials << 32) | done that the host spins on, released at system scope
             if (ls.done != 0 && A.host_result != nullptr && tid < HOST_WORDS)
                 reinterpret_cast<double *>(A.host_result)[tid] = reinterpret_cast<const double *>(&ls)[tid];
-            if (tid == 0)
-                __hip_atomic_store(A.host_progress,
-                                   ((unsigned long long)(unsigned)ls.trials << 32) | (ls.done ? 1ull : 0ull),
-                                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (tid == 0) {
+                // the release (an L2 write-back) is only needed when the result header travels with the word
+                const unsigned long long word = ((unsigned long long)(unsigned)ls.trials << 32) | (ls.done ? 1ull : 0ull);
+                if (ls.done) __hip_atomic_store(A.host_progress, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                else __hip_atomic_store(A.host_progress, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         // the terminating launch of a finished solve leaves every accumulator cleared (its own input was
         // consumed before the barrier above); an unfinished one keeps its input for the trial that follows

@@ -14,50 +14,57 @@
 
 namespace ccal {
 
-// par = f0 f1 c0 c1 k r0 r1 r2 t0 t1 t2 checker_size
-__global__ __launch_bounds__(256) void k_map_forward(const double *__restrict__ xyz, double *__restrict__ rc, int M,
-                                                      const double *__restrict__ par) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+// Intrinsic part of a map, passed BY VALUE as a kernel argument (no upload of its own): f, c, k, checker_size.
+// The extrinsic part is one (rvec, tvec) per image: rt [6, N] in device (or device-visible pinned) memory.
+// Point streams are [3, M, N] / [2, M, N] (image index = blockIdx.y); xyz_stride = 0 maps ONE [3, M] template
+// through every image's pose (what calculate_errors and the plots do, src/buildcalibrations.jl:29).
+__global__ __launch_bounds__(256) void k_map_forward(const double *__restrict__ xyz, long long xyz_stride, double *__restrict__ rc,
+                                                      int M, const MapIntr in, const double *__restrict__ rt) {
+    const int i = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
     if (i >= M) return;
-    const double f[2] = {par[0], par[1]}, c[2] = {par[2], par[3]};
-    const double r[3] = {par[5], par[6], par[7]}, t[3] = {par[8], par[9], par[10]};
+    const double *e = rt + (size_t)6 * img;
+    const double r[3] = {e[0], e[1], e[2]}, t[3] = {e[3], e[4], e[5]};
     double R[9];
     rodrigues_R(r, R);
-    const double p[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+    const double *src = xyz + (size_t)img * xyz_stride;
+    const double p[3] = {src[3 * i], src[3 * i + 1], src[3 * i + 2]};
     double o[2];
-    map_forward(p, f, c, par[4], R, t, 1.0 / par[11], o);
-    rc[2 * i] = o[0];
-    rc[2 * i + 1] = o[1];
+    map_forward(p, in.f, in.c, in.k, R, t, 1.0 / in.cs, o);
+    double *dst = rc + (size_t)2 * M * img;
+    dst[2 * i] = o[0];
+    dst[2 * i + 1] = o[1];
 }
 
-__global__ __launch_bounds__(256) void k_map_inverse(const double *__restrict__ rc, double *__restrict__ xyz, int M,
-                                                      const double *__restrict__ par) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_map_inverse(const double *__restrict__ rc, double *__restrict__ xyz, int M, const MapIntr in,
+                                                      const double *__restrict__ rt) {
+    const int i = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
     if (i >= M) return;
-    const double f[2] = {par[0], par[1]}, c[2] = {par[2], par[3]};
-    const double r[3] = {par[5], par[6], par[7]}, t[3] = {par[8], par[9], par[10]};
+    const double *e = rt + (size_t)6 * img;
+    const double r[3] = {e[0], e[1], e[2]}, t[3] = {e[3], e[4], e[5]};
     double R[9], ti[3];
     rodrigues_R(r, R);
 #pragma unroll
     for (int a = 0; a < 3; a++) ti[a] = -(R[a] * t[0] + R[3 + a] * t[1] + R[6 + a] * t[2]);
-    const double q[2] = {rc[2 * i], rc[2 * i + 1]};
+    const double *src = rc + (size_t)2 * M * img;
+    const double q[2] = {src[2 * i], src[2 * i + 1]};
     double o[3];
-    map_inverse(q, f, c, par[4], R, ti, par[11], o);
-    xyz[3 * i] = o[0];
-    xyz[3 * i + 1] = o[1];
-    xyz[3 * i + 2] = o[2];
+    map_inverse(q, in.f, in.c, in.k, R, ti, in.cs, o);
+    double *dst = xyz + (size_t)3 * M * img;
+    dst[3 * i] = o[0];
+    dst[3 * i + 1] = o[1];
+    dst[3 * i + 2] = o[2];
 }
 
 // One workgroup per image: the four sums of calculate_errors for that image.
-// par = f0 f1 c0 c1 k checker_size;  rt [6,N];  partials [4,N]
+// rt [6,N];  partials [4,N]
 __global__ __launch_bounds__(256) void k_errors(const double *__restrict__ obj, const double *__restrict__ img,
-                                                 const double *__restrict__ par, const double *__restrict__ rt,
+                                                 const MapIntr in, const double *__restrict__ rt,
                                                  const double *__restrict__ inv_pts, double *__restrict__ partials,
                                                  int n1, int n2, int S) {
     extern __shared__ __attribute__((aligned(16))) double s_xyz[];   // [3,P] projected corners
     __shared__ double s_acc[4][256];
     const int i = blockIdx.x, tid = threadIdx.x, P = n1 * n2;
-    const double f[2] = {par[0], par[1]}, c[2] = {par[2], par[3]}, k = par[4], cs = par[5];
+    const double f[2] = {in.f[0], in.f[1]}, c[2] = {in.c[0], in.c[1]}, k = in.k, cs = in.cs;
     const double r[3] = {rt[6 * i], rt[6 * i + 1], rt[6 * i + 2]};
     const double t[3] = {rt[6 * i + 3], rt[6 * i + 4], rt[6 * i + 5]};
     double R[9], ti[3];
@@ -128,10 +135,11 @@ __global__ __launch_bounds__(64) void k_errors_reduce(const double *__restrict__
 // Rectified view of one image (reference src/plot_calibration.jl:15-22,40: `warp(img, tform, axs)` with
 // tform = real2image[i] o push(.,0) o inv(ratio I)): output pixel (a, b) of the axes a0.., b0.. shows
 // the image at real2image((a, b, 0) / ratio), bilinear, `fill` outside.  par = f0 f1 c0 c1 k r t(6)
-// checker_size ratio index_offset.  One lane per output pixel and channel triple.
+// checker_size ratio index_offset (by value).  One lane per output pixel and channel triple.
 __global__ __launch_bounds__(256) void k_rectify(const uint8_t *__restrict__ img, int rows, int cols, int ch,
                                                   long long sr, long long sc, long long sk, int a0, int b0, int out_rows,
-                                                  int out_cols, const double *__restrict__ par, uint8_t *__restrict__ out) {
+                                                  int out_cols, const RectPar rp, uint8_t *__restrict__ out) {
+    const double *par = rp.v;
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if (j >= out_cols) return;
     const double f[2] = {par[0], par[1]}, c[2] = {par[2], par[3]};
@@ -159,24 +167,26 @@ __global__ __launch_bounds__(256) void k_rectify(const uint8_t *__restrict__ img
 }
 
 hipError_t launch_rectify(hipStream_t stream, const uint8_t *img, int rows, int cols, int ch, long long sr, long long sc,
-                          long long sk, int a0, int b0, int out_rows, int out_cols, const double *par, uint8_t *out) {
+                          long long sk, int a0, int b0, int out_rows, int out_cols, const RectPar &par, uint8_t *out) {
     hipLaunchKernelGGL(k_rectify, dim3((out_cols + 255) / 256, out_rows), dim3(256), 0, stream, img, rows, cols, ch, sr, sc,
                        sk, a0, b0, out_rows, out_cols, par, out);
     return hipGetLastError();
 }
 
-hipError_t launch_map_forward(hipStream_t stream, const double *xyz, double *rc, int M, const double *par) {
-    hipLaunchKernelGGL(k_map_forward, dim3((M + 255) / 256), dim3(256), 0, stream, xyz, rc, M, par);
+hipError_t launch_map_forward(hipStream_t stream, const double *xyz, long long xyz_stride, double *rc, int M, int N,
+                              const MapIntr &in, const double *rt) {
+    hipLaunchKernelGGL(k_map_forward, dim3((M + 255) / 256, N), dim3(256), 0, stream, xyz, xyz_stride, rc, M, in, rt);
     return hipGetLastError();
 }
-hipError_t launch_map_inverse(hipStream_t stream, const double *rc, double *xyz, int M, const double *par) {
-    hipLaunchKernelGGL(k_map_inverse, dim3((M + 255) / 256), dim3(256), 0, stream, rc, xyz, M, par);
+hipError_t launch_map_inverse(hipStream_t stream, const double *rc, double *xyz, int M, int N, const MapIntr &in,
+                              const double *rt) {
+    hipLaunchKernelGGL(k_map_inverse, dim3((M + 255) / 256, N), dim3(256), 0, stream, rc, xyz, M, in, rt);
     return hipGetLastError();
 }
-hipError_t launch_errors(hipStream_t stream, const double *obj, const double *img, const double *par,
+hipError_t launch_errors(hipStream_t stream, const double *obj, const double *img, const MapIntr &in,
                          const double *rt, const double *inv_pts, double *partials, int N, int n1, int n2, int S) {
     const size_t lds = sizeof(double) * 3 * (size_t)n1 * n2;
-    hipLaunchKernelGGL(k_errors, dim3(N), dim3(256), lds, stream, obj, img, par, rt, inv_pts, partials, n1, n2, S);
+    hipLaunchKernelGGL(k_errors, dim3(N), dim3(256), lds, stream, obj, img, in, rt, inv_pts, partials, n1, n2, S);
     hipLaunchKernelGGL(k_errors_reduce, dim3(1), dim3(64), 0, stream, partials, partials + (size_t)4 * N, N);
     return hipGetLastError();
 }

@@ -23,14 +23,18 @@ class _DevView:
 
 class TorchAllReduce:
     """ccal all-reduce hook backed by torch.distributed.  The device buffer handed to the
-    hook is wrapped once as a tensor; RCCL orders itself after the kernels already queued on
-    the current stream and the next kernels after it."""
+    hook is wrapped once as a tensor.  The collective is issued on the stream the library passes
+    (the context's own non-blocking stream unless `Solver(stream=...)` chose another): that is the
+    stream `k_lm_row` has just written the buffer on and the next `k_lm_trial` will read it on, so
+    the all-reduce is ordered between the two by the stream itself.  (Issued on torch's current
+    stream instead, nothing would order it against a non-blocking library stream.)"""
 
     def __init__(self, group=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.group = torch, dist, group
         self._views = {}
+        self._streams = {}
         self.calls = 0
 
     def __call__(self, ptr, n, stream):
@@ -38,7 +42,14 @@ class TorchAllReduce:
         if t is None:
             t = self.torch.as_tensor(_DevView(ptr, n), device="cuda")
             self._views[(ptr, n)] = t
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        if t.is_cuda and stream:
+            ext = self._streams.get(stream)
+            if ext is None:
+                ext = self._streams[stream] = self.torch.cuda.ExternalStream(int(stream))
+            with self.torch.cuda.stream(ext):
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        else:      # legacy default stream (handle 0): torch's current stream is the one to use
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         self.calls += 1
         return 0
 

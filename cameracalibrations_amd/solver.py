@@ -175,6 +175,32 @@ class Solver:
                                        F.f64(tvec)[1], float(checker_size), o))
         return out
 
+    def project_many(self, xyz, f, c, k, rvecs, tvecs, checker_size=1.0):
+        """xyz (M,3): one template through every pose, or (N,M,3): image n through pose n  ->  (N,M,2)."""
+        rv, rvp = F.f64(np.atleast_2d(rvecs))
+        tv, tvp = F.f64(np.atleast_2d(tvecs))
+        xyz, xp = F.f64(xyz)
+        N = rv.shape[0]
+        per_image = xyz.ndim == 3
+        M = xyz.shape[-2]
+        assert xyz.shape[-1] == 3 and tv.shape == rv.shape == (N, 3) and (not per_image or xyz.shape[0] == N)
+        out, o = F.out64(N, M, 2)
+        F.check(F.lib().ccal_project_many(self._h, xp, M, N, int(per_image), F.f64(f)[1], F.f64(c)[1], float(k), rvp, tvp,
+                                          float(checker_size), o))
+        return out
+
+    def unproject_many(self, rc, f, c, k, rvecs, tvecs, checker_size=1.0):
+        """rc (N,M,2): image n through the inverse map of pose n  ->  (N,M,3) on the board plane."""
+        rv, rvp = F.f64(np.atleast_2d(rvecs))
+        tv, tvp = F.f64(np.atleast_2d(tvecs))
+        rc, rp = F.f64(rc)
+        N, M = rc.shape[0], rc.shape[1]
+        assert rc.shape == (N, M, 2) and tv.shape == rv.shape == (N, 3)
+        out, o = F.out64(N, M, 3)
+        F.check(F.lib().ccal_unproject_many(self._h, rp, M, N, F.f64(f)[1], F.f64(c)[1], float(k), rvp, tvp,
+                                            float(checker_size), o))
+        return out
+
     def errors(self, n_corners, obj_scaled, img, f, c, k, rvecs, tvecs, checker_size, inv_pts=None):
         obj, op = F.f64(obj_scaled)
         img, ip = F.f64(img)

@@ -197,6 +197,18 @@ int  ccal_project(ccal_ctx *ctx, const double *xyz, int32_t M, const double f[2]
 int  ccal_unproject(ccal_ctx *ctx, const double *rowcol, int32_t M, const double f[2],
                     const double c[2], double k, const double rvec[3], const double tvec[3],
                     double checker_size, double *xyz);
+/* The same maps for N images in ONE call (what `c.(objpoints, i)` over all i does in calculate_errors and the
+ * plots, src/buildcalibrations.jl:29,46): image n goes through pose n of rvecs/tvecs [3,N].
+ * ccal_project_many: xyz is [3,M,N] (per_image != 0) or one [3,M] template mapped through every pose
+ * (per_image == 0); rowcol [2,M,N].  ccal_unproject_many: rowcol [2,M,N] -> xyz [3,M,N].
+ * None of the map / metric / warp entry points allocates device memory per call (the context keeps
+ * grow-only scratch); calls of up to a few thousand points do not copy at all (pinned staging). */
+int  ccal_project_many(ccal_ctx *ctx, const double *xyz, int32_t M, int32_t N, int32_t per_image,
+                       const double f[2], const double c[2], double k, const double *rvecs,
+                       const double *tvecs, double checker_size, double *rowcol);
+int  ccal_unproject_many(ccal_ctx *ctx, const double *rowcol, int32_t M, int32_t N, const double f[2],
+                         const double c[2], double k, const double *rvecs, const double *tvecs,
+                         double checker_size, double *xyz);
 /* calculate_errors (src/buildcalibrations.jl:37-67): out = reprojection, projection,
  * distance, inverse.  obj_scaled [3,P] Float64 (template * checker_size), img [2,P,N] Float64,
  * inv_pts [2,S,N] caller-supplied round-trip samples (the reference uses the global RNG). */

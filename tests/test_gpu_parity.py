@@ -43,6 +43,7 @@ def _oracle_init(wl):
 
 
 CASES = [("C1", 16), ("C2", 37), ("REF", 9), ("C5", 7), ("C2", 1), ("C1", 3)]
+FULL_CASES = CASES + [("C1", 100)]      # BASELINE.json configs[1] at its stated size: 100 images x 9x6, pinhole
 
 
 @pytest.mark.parametrize("name,n", CASES)
@@ -106,7 +107,7 @@ def test_closed_form_initialisation(name, n):
     assert np.abs(grt[:, 3:] - rt0[:, 3:]).max() < 1e-6
 
 
-@pytest.mark.parametrize("name,n", CASES)
+@pytest.mark.parametrize("name,n", FULL_CASES)
 @pytest.mark.parametrize("crit", [REF, TIGHT])
 def test_full_fit_matches_oracle(name, n, crit):
     """The whole calibrateCamera replacement, device init + device LM, vs the oracle.
@@ -614,3 +615,131 @@ def test_p2p_selftest_world1():
         s.init_p2p(1, 0, 8, lambda b: [b])
         s.p2p_selftest(12)
         s.p2p_selftest(3)
+
+
+# ---- BASELINE.json configs[3]: the real 1000-image C3 set sharded over ranks, against the ORACLE -------------------
+_C3_ORACLE = {}
+
+
+def _c3_oracle():
+    if not _C3_ORACLE:
+        wl = syn.named_workload("C3")
+        _C3_ORACLE.update(wl=wl, ro=_oracle(wl, REF, nthreads=8))
+    return _C3_ORACLE["wl"], _C3_ORACLE["ro"]
+
+
+def _c3_shard_worker(rank, world, port, out, transport, explicit_stream):
+    import torch
+    import torch.distributed as dist
+    from cameracalibrations_amd.distributed import TorchAllReduce, allgather_bytes_via_torch, shard_range
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["CCAL_P2P_TIMEOUT_MS"] = "20000"
+    torch.cuda.set_device(0)                               # the ranks share the one GPU of the test box
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        wl = syn.named_workload("C3")
+        lo, hi = shard_range(wl.n_images, world, rank)
+        kw = dict(stream=torch.cuda.current_stream().cuda_stream) if explicit_stream else {}
+        with Solver(0, **kw) as s:                         # no stream=: the context's own NON-BLOCKING stream
+            s.set_problem(wl.obj, hi - lo, wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=REF[0], eps=REF[1])
+            s.set_image_points(torch.from_numpy(wl.img[lo:hi]).cuda())
+            if transport == "p2p":
+                s.init_p2p(world, rank, wl.n_images, allgather_bytes_via_torch())
+            else:
+                s.set_allreduce(TorchAllReduce(), world, rank, wl.n_images)
+            st, r = s.calibrate()
+            st2, r2 = s.calibrate()                        # again (graph replay with the peers for p2p)
+            assert np.array_equal(r["intr"], r2["intr"]) and r["rms"] == r2["rms"] and r["iters"] == r2["iters"]
+            dist.barrier()
+        out[rank] = dict(status=st, lo=lo, hi=hi, intr=r["intr"].tolist(), rvecs=r["rvecs"].tolist(), tvecs=r["tvecs"].tolist(),
+                         rms=r["rms"], iters=r["iters"], sweeps=r["sweeps"], rejected=r["rejected"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,transport", [(2, "p2p"), (4, "p2p"), (2, "torch-hook")])
+def test_c3_sharded_over_ranks_matches_oracle(world, transport):
+    """BASELINE.json configs[3]: the SAME 1000-image x 9x6 set of configs[2], sharded per image over 2 / 4 ranks (sharing
+    the test box's one GPU; at most 6 processes may use it, so 8 ranks are covered by the CPU world-size tests), through
+    the direct exchange and through the torch.distributed hook on the context's own non-blocking stream (the hook must
+    order itself on the stream it is handed).  Checked against the ORACLE, not against the single-GPU device fit:
+    RMS to 1e-8 px, same accepted-iteration count, parameters to the full-fit tolerances."""
+    import socket
+
+    import torch.multiprocessing as mp
+    wl, ro = _c3_oracle()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_c3_shard_worker, args=(world, port, out, "p2p" if transport == "p2p" else "torch", False), nprocs=world, join=True)
+    assert set(out.keys()) == set(range(world))
+    a = out[0]
+    for r in range(1, world):
+        assert out[r]["intr"] == a["intr"] and out[r]["rms"] == a["rms"] and out[r]["iters"] == a["iters"]   # replicated state
+    assert a["iters"] == ro["iters"] and a["rejected"] == 0
+    assert abs(a["rms"] - ro["rms"]) < 1e-8
+    intr = np.array(a["intr"])
+    assert np.abs(intr[:4] - ro["intr"][:4]).max() / ro["intr"][1] < 1e-6 and np.abs(intr[4:] - ro["intr"][4:]).max() < 1e-5
+    rv = np.vstack([np.array(out[r]["rvecs"]) for r in range(world)])
+    tv = np.vstack([np.array(out[r]["tvecs"]) for r in range(world)])
+    assert rv.shape == (1000, 3)
+    assert np.abs(rv - ro["rvecs"]).max() < 1e-5 and np.abs(tv - ro["tvecs"]).max() < 1e-4
+
+
+def test_c3_single_gpu_matches_oracle_full_size():
+    """BASELINE.json configs[2] at full size against the oracle (the sharded test's single-GPU twin)."""
+    wl, ro = _c3_oracle()
+    with _solver(wl, REF) as s:
+        st, r = s.calibrate()
+    assert r["iters"] == ro["iters"] and abs(r["rms"] - ro["rms"]) < 1e-8
+    assert np.abs(r["intr"][:4] - ro["intr"][:4]).max() / ro["intr"][1] < 1e-6
+    assert np.abs(r["rvecs"] - ro["rvecs"]).max() < 1e-5 and np.abs(r["tvecs"] - ro["tvecs"]).max() < 1e-4
+
+
+def test_uneven_shards_across_the_exchange_threshold():
+    """2561 images on two ranks = 1281 + 1280: 321 and 320 workgroups, one on each side of the limit up to which the
+    exchange is fused into the trial's prologue.  The mode is chosen from the GLOBAL size, so both ranks take the same
+    path (a mixed pair would stop exchanging at different trials); the solve is run twice (graph replay, then the
+    surplus launches of the first solve must not have left anything behind)."""
+    import socket
+
+    import torch.multiprocessing as mp
+    n_total = 2561
+    wl = syn.named_workload("C2", n_images=n_total)
+    with _solver(wl, REF) as s:
+        _, base = s.calibrate()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_two_rank_worker, args=(2, port, n_total, out, "p2p"), nprocs=2, join=True)
+    a, b = out[0], out[1]
+    assert (a["hi"] - a["lo"], b["hi"] - b["lo"]) == (1281, 1280)
+    assert a["intr"] == b["intr"] and a["iters"] == base["iters"] and abs(a["rms"] - base["rms"]) < 1e-12
+
+
+def test_many_image_maps_match_per_image_calls_and_oracle():
+    """ccal_project_many / ccal_unproject_many (one call for all images, per-image poses) == the per-image entry points
+    == the oracle's Julia-map restatement (src/meta.jl:27-76); small calls (pinned zero-copy path) and large ones
+    (device scratch path)."""
+    rng = np.random.default_rng(4)
+    f, c, k = np.array([1600.0, 1610.0]), np.array([750.0, 1000.0]), -0.11
+    for N, M in ((3, 7), (40, 54), (300, 150)):
+        rv = rng.uniform(-0.4, 0.4, (N, 3))
+        tv = np.c_[rng.uniform(-2, 2, (N, 2)), rng.uniform(9, 15, N)]
+        xyz = np.c_[rng.uniform(0, 8, (M, 2)), np.zeros(M)]
+        with Solver(0) as s:
+            rc = s.project_many(xyz, f, c, k, rv, tv, 2.5)
+            back = s.unproject_many(rc, f, c, k, rv, tv, 2.5)
+            per_img = s.project_many(np.broadcast_to(xyz, (N, M, 3)).copy(), f, c, k, rv, tv, 2.5)
+            one = np.stack([s.project(xyz, f, c, k, rv[i], tv[i], 2.5) for i in range(min(N, 5))])
+        assert rc.shape == (N, M, 2) and back.shape == (N, M, 3)
+        assert np.array_equal(per_img, rc) and np.array_equal(one, rc[: one.shape[0]])
+        for i in range(min(N, 5)):
+            assert np.abs(rc[i] - orc.map_forward(xyz, f, c, k, rv[i], tv[i], 2.5)).max() < 1e-9
+            assert np.abs(back[i] - orc.map_inverse(rc[i], f, c, k, rv[i], tv[i], 2.5)).max() < 1e-8
+        assert np.abs(back - xyz[None]).max() < 1e-8          # round trip on the board plane
