@@ -5,6 +5,7 @@
 // gfx950 kernels.  There is no CPU fallback: without a HIP device every entry fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -368,10 +369,11 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
     if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));   // `obj` may be released by the caller after return
     c->P = P; c->N = N; c->width = width; c->height = height; c->aspect = aspect; c->flags = flags;
     c->max_iter = max_iter; c->eps = eps;
-    c->acc_R = lm_acc_replicas(lm_sweep_blocks(N));
+    const int sweep_grid = std::min(lm_sweep_blocks(N), lm_max_grid());
+    c->acc_R = lm_acc_replicas(sweep_grid);
     if (const char *r = getenv("CCAL_ACC_REPLICAS")) {      // experiments: 1, 2, 4, ... 64
         const int v = atoi(r);
-        if (v >= 1 && v <= ACC_MAX_REPLICAS && (v & (v - 1)) == 0 && (lm_sweep_blocks(N) + v - 1) / v <= 2000) c->acc_R = v;
+        if (v >= 1 && v <= ACC_MAX_REPLICAS && (v & (v - 1)) == 0 && (sweep_grid + v - 1) / v <= 2000) c->acc_R = v;
     }
     c->acc_dirty = true;               // the buffer layout depends on the replica count
     c->have_problem = true;

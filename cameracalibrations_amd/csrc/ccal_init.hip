@@ -491,9 +491,7 @@ __device__ __forceinline__ void rodrigues_inv(const double R[9], double r[3]) {
 
 // residual-only / residual+Jacobian pass of the per-view LM
 __device__ double view_error(const float *obj, const float2 *img, int P, int lane, const double rt[6],
-                             const double in[NINTR]) {
-    double R[9], K[9];
-    rodrigues_RK(rt, R, K);
+                             const double R[9], const double in[NINTR]) {
     double s = 0.0;
     for (int c0 = 0; c0 < P; c0 += 64) {
         const int p = c0 + lane;
@@ -510,9 +508,8 @@ __device__ double view_error(const float *obj, const float2 *img, int P, int lan
 
 // JtJ (6x6 packed), Jt e and ||e||^2 of one view through the packed 8-column MFMA Gram
 __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int lane, const double rt[6],
-                                 const double in[NINTR], double *tile, double *Gs, double JtJ[21], double JtErr[6]) {
-    double R[9], K[9];
-    rodrigues_RK(rt, R, K);
+                                 const double R[9], const double K[9], const double in[NINTR], double *tile, double *Gs,
+                                 double JtJ[21], double JtErr[6]) {
     d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     for (int c0 = 0; c0 < P; c0 += 64) {
         const int p = c0 + lane;
@@ -611,6 +608,11 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
 #pragma unroll
     for (int k = 0; k < 21; k++) JtJ[k] = 0.0;
     ISTAMP(2);
+    // lambda = 10^lambdaLg10 as OpenCV forms it, exp(lambdaLg10 * log(10)): tabulated once (lane l holds entry l)
+    // instead of one double-precision exp per step
+    const double pow10_l = exp((double)((lane < 33 ? lane : 32) - 16) * log(10.0));
+    double R[9], K[9];                           // rotation of the current rt and its left Jacobian: one evaluation per
+    rodrigues_RK(rt, R, K);                      // new point, shared by the error pass and the Jacobian pass that follows it
     int lambdaLg10 = -3, iters = 0, state = 1;   // 1 STARTED, 2 CALC_J, 3 CHECK_ERR
     int n_j = 0, n_e = 0;
     (void)n_j; (void)n_e;
@@ -646,16 +648,18 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
             for (int k = 0; k < 21; k++) A[k] = JtJ[k];
 #pragma unroll
             for (int k = 0; k < 6; k++) d[k] = JtErr[k];
-            damp_diag<6>(A, exp((double)lambdaLg10 * log(10.0)));
+            damp_diag<6>(A, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pow10_l), lambdaLg10 + 16),
+                                             __builtin_amdgcn_readlane(__double2loint(pow10_l), lambdaLg10 + 16)));
             double ip6[6];
             const bool pd = chol_packed<6>(A, ip6);
             fwd_subst<6>(A, ip6, d);
             bwd_subst<6>(A, ip6, d);
 #pragma unroll
             for (int k = 0; k < 6; k++) rt[k] = prev[k] - (pd ? d[k] : 0.0);
+            rodrigues_RK(rt, R, K);
         }
-        if (state == 2) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, in, s_tile, s_G, JtJ, JtErr)); n_j++; }
-        else { errNorm = sqrt(view_error(obj, img_i, P, lane, rt, in)); n_e++; }
+        if (state == 2) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_tile, s_G, JtJ, JtErr)); n_j++; }
+        else { errNorm = sqrt(view_error(obj, img_i, P, lane, rt, R, in)); n_e++; }
     }
     ISTAMP(3);
     ICOUNT(4, n_j); ICOUNT(5, n_e); ICOUNT(6, iters);

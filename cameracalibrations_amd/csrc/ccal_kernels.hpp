@@ -10,6 +10,7 @@ namespace ccal {
 
 // ccal_lm.hip
 int lm_sweep_blocks(int N);
+int lm_max_grid();               // workgroups of k_lm_trial resident on the current device (the sweep grid is capped there)
 struct TrialLaunch {              // one launch of k_lm_trial (see ccal_lm.hip)
     const float *obj = nullptr, *img = nullptr;
     double *blk = nullptr;

@@ -35,6 +35,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -469,8 +471,11 @@ __device__ void lm_boot(LmState *ls, const LmInit &init, const double *intr0, in
 // the LM advance the prologue stores the row into the peers' inboxes (workgroup 0) and adds the
 // peers' rows from the local inbox in rank order (every workgroup) -- the whole all-reduce, with
 // no launch of its own.  The first launch of a solve takes the next sequence number.
+#ifndef CCAL_TRIAL_MIN_WAVES
+#define CCAL_TRIAL_MIN_WAVES 2   /* two workgroups per CU (LDS-limited anyway): keep the register file share of two waves per SIMD */
+#endif
 template <bool XCHG>
-__global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
+__global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(const TrialArgs A) {
     __shared__ __attribute__((aligned(16))) double s_wave[WAVES * TILE_D];
     __shared__ __attribute__((aligned(16))) double s_red[WAVES * NRED];
     __shared__ __attribute__((aligned(16))) double s_rs[NRED];
@@ -486,9 +491,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = A.N, P = A.P;
-    const int img_i = blockIdx.x * WAVES + wave;
-    const bool active = img_i < N;              // wave-uniform
-    const int ii = active ? img_i : N - 1;      // clamped: idle waves mirror the last image, store nothing
+#ifdef CCAL_STAMPS
+    asm volatile("" ::"s"(N), "s"(A.st));        // the kernel arguments have arrived
+    STAMP(13);
+#endif
+    // A workgroup sweeps the image groups g = blockIdx.x, blockIdx.x + gridDim.x, ... (four images each, one per
+    // wave): the grid is capped at what the chip holds resident, so that the prologue above the loop -- state,
+    // accumulators, LM advance -- runs once per resident workgroup, not once per four images.
+    const int n_groups = (N + WAVES - 1) / WAVES;
+    int g = blockIdx.x;
+    int img_i = g * WAVES + wave;
+    bool active = img_i < N;                    // wave-uniform
+    int ii = active ? img_i : N - 1;            // clamped: idle waves mirror the last image, store nothing
     const size_t acc_buf = (size_t)A.R * ACC_ROW;   // int64 words per accumulator buffer
 
     // ---- 0. loads that do not depend on the LM state are issued up front: the previous state, the
@@ -609,19 +623,34 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
     double *Gs = W + W_G, *Hs = W + W_HEAD, *Ys = W + W_Y;
     double *red = s_red + wave * NRED;
 
-    // ---- 2. block head of the accepted point -> wave-uniform registers ----
-    // lane j holds block word j (hsel) and word 64 + j (hselb); uniform values are pulled out with
-    // v_readlane, no LDS staging of the block
-    const double hsel = par ? h1a : h0a, hselb = par ? h1b : h0b;
+    const double aspect = ls.aspect, lam_next = ls.lam_next;
+    // does the reduced-system entry this lane will assemble belong to free parameters only?
+    // lanes 0..44: S0(oa, ob); 45..53: dA(a); 54..62: gs(a); 63: the error
+    const int ka = lane < RED_DA ? oa : (lane < RED_ERR ? (lane - RED_DA) % NINTR : 0);
+    const int kb = lane < RED_DA ? ob : ka;
+    const bool keep = lane >= RED_ERR || (ls.mask[ka] != 0 && ls.mask[kb] != 0);
+    double in[NINTR];                             // the intrinsics this sweep evaluates: candidate, or (INIT / RESCHUR) accepted
+    {
+        const double *src = (mode == MODE_EVAL) ? ls.intr_cand : ls.intr_prev;
+#pragma unroll
+        for (int a = 0; a < NINTR; a++) in[a] = src[a];
+    }
     auto bcast = [](double v, int src) -> double {
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
                                 __builtin_amdgcn_readlane(__double2loint(v), src));
     };
+
+    for (bool first_group = true;; first_group = false) {
+    const int g_next = g + (int)gridDim.x;
+    const bool last_group = g_next >= n_groups;   // workgroup-uniform
+    // ---- 2. block head of the accepted point -> wave-uniform registers ----
+    // lane j holds block word j (hsel) and word 64 + j (hselb); uniform values are pulled out with
+    // v_readlane, no LDS staging of the block
+    const double hsel = par ? h1a : h0a, hselb = par ? h1b : h0b;
     double e6[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) e6[k] = bcast(hselb, BLK_EXT - 64 + k);
     double dnum = 0.0, dden = 0.0;
-    double in[NINTR];
     if (mode == MODE_EVAL) {
         // delta_i = C_l^-1 (h - B^T delta_int) = u_h - U_B delta_int, U kept by the last sweep one value per
         // lane: lane 16 k + j multiplies U[j][k] by (-delta_int[j] | +1 for j = 9 | 0), a DPP sum inside each row
@@ -639,19 +668,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
             dnum += dk * dk;
             e6[k] -= dk;
         }
-#pragma unroll
-        for (int a = 0; a < NINTR; a++) in[a] = ls.intr_cand[a];
-    } else {
-        // MODE_INIT / MODE_RESCHUR: (re-)evaluate the accepted point itself
-#pragma unroll
-        for (int a = 0; a < NINTR; a++) in[a] = ls.intr_prev[a];
     }
-    const double aspect = ls.aspect, lam_next = ls.lam_next;
-    // does the reduced-system entry this lane will assemble belong to free parameters only?
-    // lanes 0..44: S0(oa, ob); 45..53: dA(a); 54..62: gs(a); 63: the error
-    const int ka = lane < RED_DA ? oa : (lane < RED_ERR ? (lane - RED_DA) % NINTR : 0);
-    const int kb = lane < RED_DA ? ob : ka;
-    const bool keep = lane >= RED_ERR || (ls.mask[ka] != 0 && ls.mask[kb] != 0);
     wave_lds_sync();                              // head consumed: the tile may overwrite it
 
     // ---- 3. rows -> LDS -> f64 MFMA Gram ----
@@ -672,15 +689,30 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
         double mu[NCOL], mv[NCOL];
         point_rows_K(M, (double)uv.x, (double)uv.y, R, K, e6 + 3, in, aspect, mu, mv);
         STAMP(4);
+#ifdef CCAL_HALF_TILE
+        // half-size tile (occupancy): lanes 0..31 stage their rows, Gram of those corners, then lanes 32..63
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int n_h = min(32, P - c0 - 32 * h);
+            if (n_h > 0) {
+                if ((lane >> 5) == h) tile_store_rows(W, lane, mu, mv, valid);
+                wave_lds_sync();
+                tile_gram(W, lane, n_h, acc0, acc1);
+                wave_lds_sync();
+            }
+        }
+#else
         tile_store_rows(W, lane, mu, mv, valid);
         wave_lds_sync();
         STAMP(5);
         tile_gram(W, lane, min(64, P - c0), acc0, acc1);
         wave_lds_sync();                          // operands are in registers: the tile is free
+#endif
     }
     gram_to_lds(Gs, lane, acc0, acc1);
     STAMP(6);
     wave_lds_sync();
+
 
     if (A.gram_out != nullptr && active) {
 #pragma unroll
@@ -738,12 +770,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
         } else {
             v = err_i;                                    // lane 63
         }
-        red[lane] = (active && keep) ? v : 0.0;   // fixed parameters leave zero rows / columns, dA = 0 and g = 0
+        // this wave's sums over its images (wave-private LDS; fixed parameters leave zero rows / columns, dA = 0, g = 0)
+        const double vv = (active && keep) ? v : 0.0;
+        red[lane] = first_group ? vv : red[lane] + vv;
         if (lane < 4) {
             const double w = lane == 0 ? dnum : (lane == 1 ? dden : (lane == 2 ? ((pd && finite) ? 0.0 : 1.0) : 0.0));
-            red[64 + lane] = active ? w : 0.0;
+            const double ww = active ? w : 0.0;
+            red[64 + lane] = first_group ? ww : red[64 + lane] + ww;
         }
     }
+    if (last_group) {
     __syncthreads();
     if (tid < NRED) {
         double s = s_red[tid];
@@ -751,6 +787,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
         for (int w = 1; w < WAVES; w++) s += s_red[w * NRED + tid];   // fixed order inside the workgroup
         // ... and exact, order-independent across workgroups: limbs added with integer atomics
         acc_add(A.acc + ((size_t)(A.k % 3) * A.R + (blockIdx.x & (A.R - 1))) * ACC_ROW, tid, s);
+    }
     }
     STAMP(9);
 
@@ -772,6 +809,24 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_trial(const TrialArgs A) {
         double *bo = A.blk + ((size_t)cand * N + ii) * BLK;
         bo[lane] = Hs[lane];
         bo[64 + lane] = Hs[64 + lane];
+    }
+    if (last_group) break;
+    g = g_next;
+    // next group of this workgroup: its images' blocks and first corners (requesting them earlier, behind the
+    // factorisation, changed nothing: measured)
+    img_i = g * WAVES + wave;
+    active = img_i < N;
+    ii = active ? img_i : N - 1;
+    img2 = reinterpret_cast<const float2 *>(A.img) + (size_t)ii * P;
+    if (A.first) {
+        h0b = (lane >= BLK_EXT - 64 && lane < BLK_EXT - 64 + 6) ? A.ext0[(size_t)ii * A.ext0_stride + lane - (BLK_EXT - 64)] : 0.0;
+    } else {
+        const double *bp = A.blk + ((size_t)par * N + ii) * BLK;     // the accepted parity is known by now
+        if (par) { h1a = bp[lane]; h1b = bp[64 + lane]; } else { h0a = bp[lane]; h0b = bp[64 + lane]; }
+    }
+    uv = img2[pc0];
+    m0 = A.obj[3 * pc0]; m1 = A.obj[3 * pc0 + 1]; m2 = A.obj[3 * pc0 + 2];
+    wave_lds_sync();                              // the block has left LDS: the next group's tile may overwrite it
     }
     STAMP(10);
     STAMP_RT(31);
@@ -831,6 +886,24 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_exchange(const long long *__r
 // ---------------------------------------------------------------------------------------
 int lm_sweep_blocks(int N) { return (N + WAVES - 1) / WAVES; }
 
+// Workgroups of k_lm_trial the current device keeps resident (occupancy query x compute units; CCAL_MAX_GRID
+// overrides).  Both instantiations use the same resources up to a few SGPRs.
+int lm_max_grid() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (cached[dev] > 0) return cached[dev];
+    int per_cu = 0, cus = 0;
+    if (const char *e = getenv("CCAL_MAX_GRID")) {
+        const int v = atoi(e);
+        if (v > 0) return cached[dev] = v;
+    }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lm_trial<true>, WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    (void)hipGetLastError();
+    return cached[dev] = per_cu * cus;
+}
+
 hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     if (t.acc == nullptr || t.R < 1 || t.R > ACC_MAX_REPLICAS || (t.R & (t.R - 1)) != 0) return hipErrorInvalidValue;
     TrialArgs a;
@@ -841,7 +914,8 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     a.final_only = t.final_only;
     a.xchg_fused = 0;
     memset(&a.p2p, 0, sizeof a.p2p);
-    const int grid = t.final_only ? 1 : lm_sweep_blocks(t.N);
+    // sweep grid: one workgroup per four images up to what the chip keeps resident; beyond that the workgroups loop
+    const int grid = t.final_only ? 1 : std::min(lm_sweep_blocks(t.N), lm_max_grid());
     if (t.p2p != nullptr) {
         a.p2p = *t.p2p;
         a.xchg_fused = t.xchg_fused;

@@ -144,8 +144,10 @@ CCAL_HD void rodrigues_RK(const double r[3], double R[9], double K[9]) {
     const double t2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
     double sc, c, a, b;   // sc = sin(th)/th
     if (t2 <= 10.0) {
-        // th <= pi (every rotation): alternating Taylor series in th^2, 18 terms, absolute error
-        // < 1e-16; three independent Horner chains, no sqrt / sincos / divide
+        // th <= pi (every rotation): alternating Taylor series in th^2, three independent Horner chains, no
+        // sqrt / sincos / divide.  18 terms reach an absolute error < 1e-16 up to th^2 = 10; rotations of at
+        // most one radian (th^2 <= 1: every pose of an ordinary calibration set) need only 11
+        // (first neglected term 1 / 23! = 4e-23): the branch is wave-uniform.
         //   sc = sum (-t2)^k / (2k+1)!   a = sum (-t2)^k / (2k+2)!   b = sum (-t2)^k / (2k+3)!
         sc = 0.0; a = 0.0; b = 0.0;
         // 1/(2k+1)!, highest order first; the other two tables follow by division (folded at compile time)
@@ -154,12 +156,24 @@ CCAL_HD void rodrigues_RK(const double r[3], double R[9], double K[9]) {
                                1.0 / 2.585201673888498e22, 1.0 / 5.109094217170944e19, 1.0 / 1.21645100408832e17,
                                1.0 / 3.55687428096e14, 1.0 / 1.307674368e12, 1.0 / 6227020800.0, 1.0 / 39916800.0,
                                1.0 / 362880.0, 1.0 / 5040.0, 1.0 / 120.0, 1.0 / 6.0, 1.0};
+        if (t2 > 1.0) {
 #pragma unroll
-        for (int k = 0; k < 18; k++) {
-            const int ord = 17 - k;                       // power of (-t2)
-            const double cs = CS[k];                      // 1/(2 ord + 1)!
-            const double ca = cs / (double)(2 * ord + 2); // 1/(2 ord + 2)!
-            const double cb = ca / (double)(2 * ord + 3); // 1/(2 ord + 3)!
+            for (int k = 0; k < 7; k++) {
+                const int ord = 17 - k;                       // power of (-t2)
+                const double cs = CS[k];                      // 1/(2 ord + 1)!
+                const double ca = cs / (double)(2 * ord + 2); // 1/(2 ord + 2)!
+                const double cb = ca / (double)(2 * ord + 3); // 1/(2 ord + 3)!
+                sc = sc * (-t2) + cs;
+                a = a * (-t2) + ca;
+                b = b * (-t2) + cb;
+            }
+        }
+#pragma unroll
+        for (int k = 7; k < 18; k++) {
+            const int ord = 17 - k;
+            const double cs = CS[k];
+            const double ca = cs / (double)(2 * ord + 2);
+            const double cb = ca / (double)(2 * ord + 3);
             sc = sc * (-t2) + cs;
             a = a * (-t2) + ca;
             b = b * (-t2) + cb;

@@ -16,7 +16,12 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int TILE_LD = 34;           // doubles per corner: 2 rows x 16 columns + 2 pad (272 B:
                                       // 16-B aligned b128 stores, 8 consecutive lanes hit 32 distinct banks)
-constexpr int TILE_D = 64 * TILE_LD;  // doubles per wave tile (17408 B)
+#ifdef CCAL_HALF_TILE
+constexpr int TILE_PTS = 32;          // corners staged at a time (two rounds per 64-lane pass): 8.7 KB per wave
+#else
+constexpr int TILE_PTS = 64;
+#endif
+constexpr int TILE_D = TILE_PTS * TILE_LD;  // doubles per wave tile (17408 B for 64 corners)
 
 // DPP move of a double (two 32-bit halves); CTRL is a v_mov_b32_dpp control word
 template <int CTRL>
@@ -70,10 +75,12 @@ __device__ __forceinline__ double wave_max(double v) {
     return t;
 }
 
-// One lane stores its corner's two 16-wide rows (zeros when !valid) into the wave's tile.
+// One lane stores its corner's two 16-wide rows (zeros when !valid) into the wave's tile.  Value selects, not two
+// exec-masked store blocks: a branch would keep all 32 row values live up to it (+40 VGPRs, spills; measured),
+// whereas selects let every value be stored as soon as it is computed.
 __device__ __forceinline__ void tile_store_rows(double *tile, int lane, const double mu[16], const double mv[16],
                                                 bool valid) {
-    double2 *dst = reinterpret_cast<double2 *>(tile + lane * TILE_LD);
+    double2 *dst = reinterpret_cast<double2 *>(tile + (lane & (TILE_PTS - 1)) * TILE_LD);
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         dst[c] = valid ? make_double2(mu[2 * c], mu[2 * c + 1]) : make_double2(0.0, 0.0);

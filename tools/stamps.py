@@ -35,18 +35,30 @@ with Solver(0) as s:
         L.ccal_debug_stamps(buf)
         t = np.array(buf[:11], dtype=np.int64)
         d = np.diff(t)
+        rt = 0
         print("total cycles", t[10] - t[0], "(%.2f us at 2.4 GHz)" % ((t[10] - t[0]) / 2400.0))
         for n, v in zip(names[1:], d):
             print(f"   {n:24s} {v:7d}")
         rt = int(buf[31]) - int(buf[30])
         if rt > 0:
             print("   shader clock over this wave's lifetime: %.0f MHz (s_memtime / s_memrealtime x 100 MHz)" % (100.0 * (int(buf[10]) - int(buf[0])) / rt))
+        print("   entry -> kernel arguments in SGPRs:", int(buf[13]) - int(buf[0]), "cycles")
         t = np.array(buf[:13], dtype=np.int64)
         print("   prologue: loads -> barrier", t[11] - t[0], "decode (+exchange)", t[12] - t[11], "advance+sync", t[1] - t[12])
         a = np.array(buf[16:20], dtype=np.int64)
         print("   advance: state machine", a[0] - t[12], "assemble S", a[1] - a[0], "chol9", a[2] - a[1], "solves", a[3] - a[2],
               "tail", t[1] - a[3])
 
+    # machine-readable summary of the last repetition (copied to profiles/r02_wave_stamps.json for block 7)
+    import json
+    phases = dict(zip(names[1:], [int(v) for v in d]))
+    clock = 100.0 * (int(buf[10]) - int(buf[0])) / rt if rt > 0 else None
+    json.dump({"workload": wl.name, "N": wl.n_images, "P": wl.n_points, "block": BLOCK, "wave_cycles": int(buf[10]) - int(buf[0]),
+               "clock_mhz": clock, "phases_cycles": phases,
+               "prologue_cycles": {"loads_to_barrier": int(t[11] - t[0]), "decode": int(t[12] - t[11]), "advance_and_sync": int(t[1] - t[12])},
+               "what": "s_memtime stamps of wave 0 of one workgroup in the last sweeping launch of a solve (diagnostic build, "
+                       "-DCCAL_STAMPS: the stamps and their scheduling barriers add roughly 5-10 % to the wave's cycles)"},
+              open(os.path.join(ROOT, "gpurun_out", "wave_stamps_block%d.json" % BLOCK), "w"), indent=1)
     ib = (C.c_ulonglong * 16)()
     L.ccal_debug_init_stamps.restype = C.c_int
     L.ccal_debug_init_stamps(ib)
