@@ -875,6 +875,21 @@ void ccal_thread_cleanup(void) {
     t_multi.clear();
 }
 
+}  // extern "C"
+
+// The cached contexts of a host thread die with the thread (a Julia task pool or a Python worker thread that
+// comes and goes would otherwise leak one stream, ~25 device buffers and a launch graph per thread).  A
+// thread_local object's destructor runs at thread exit -- for the main thread before any atexit handler, i.e.
+// while the HIP runtime is still up.
+namespace {
+struct ThreadCacheGuard {
+    ~ThreadCacheGuard() { ccal_thread_cleanup(); }
+};
+thread_local ThreadCacheGuard t_cache_guard;
+}  // namespace
+
+extern "C" {
+
 int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int32_t width, int32_t height,
                    double aspect, uint32_t flags, int32_t max_iter, double eps, int32_t device, double K4[4],
                    double dist5[5], double *rvecs, double *tvecs, double *rms, int32_t *iters, ccal_stats *stats) {
@@ -885,6 +900,7 @@ int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int
     if (!c) {
         if ((rc = ccal_create(device, &c)) < 0) return rc;
         t_cached[device] = c;
+        (void)&t_cache_guard;          // instantiate this thread's guard: the cache is released at thread exit
     }
     double intr[9];
     int lm_rc = 0;
@@ -970,6 +986,7 @@ static MultiSet *multi_get(int n_dev, const int32_t *dev_ids) {
         return nullptr;
     }
     t_multi.push_back(m);
+    (void)&t_cache_guard;
     return &t_multi.back();
 }
 

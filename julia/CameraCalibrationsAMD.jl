@@ -1,6 +1,6 @@
 # CameraCalibrationsAMD.jl -- thin `ccall` binding of libccal_hip.so (include/ccal.h).
 #
-# UNTESTED IN THIS REPOSITORY: the build image has no Julia.  The Python mirror
+# UNTESTED IN THIS REPOSITORY: the build image has no Julia -- none of this file has ever been parsed or run.  The Python mirror
 # (cameracalibrations_amd/solver.py, tested on MI355X) makes exactly the same calls with the
 # same array layouts; keep the two in step.
 #
@@ -125,6 +125,96 @@ function detect_corners(c::Context, gray::Matrix{UInt8}, n_corners)
                 c.h, gray, rows, cols, 1, rows, n1, n2, corners, found, C_NULL))
     found[] == 0 && return missing
     return reshape([(corners[1, i], corners[2, i]) for i in 1:n1*n2], n1, n2)
+end
+
+# ---- many-image maps: image n through pose n, one call (include/ccal.h ccal_project_many / ccal_unproject_many) ----
+function project_many(c::Context, xyz::Array{Float64}, f, cc, k, rvecs::Matrix{Float64}, tvecs::Matrix{Float64}, checker_size)
+    N = size(rvecs, 2); per_image = ndims(xyz) == 3; M = size(xyz, 2); out = zeros(Float64, 2, M, N)
+    check(ccall((:ccal_project_many, LIB), Int32,
+                (Ptr{Cvoid}, Ptr{Float64}, Int32, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}),
+                c.h, xyz, M, N, per_image ? 1 : 0, Float64[f...], Float64[cc...], Float64(k), rvecs, tvecs, Float64(checker_size), out))
+    return out
+end
+
+function unproject_many(c::Context, rowcol::Array{Float64,3}, f, cc, k, rvecs::Matrix{Float64}, tvecs::Matrix{Float64}, checker_size)
+    M, N = size(rowcol, 2), size(rowcol, 3); out = zeros(Float64, 3, M, N)
+    check(ccall((:ccal_unproject_many, LIB), Int32,
+                (Ptr{Cvoid}, Ptr{Float64}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}),
+                c.h, rowcol, M, N, Float64[f...], Float64[cc...], Float64(k), rvecs, tvecs, Float64(checker_size), out))
+    return out
+end
+
+# ---- the reference's public surface on top of the calls above (src/CameraCalibrations.jl:18 exports
+#      fit, Calibration, RowCol, XYZ, rectification) ------------------------------------------------------
+const RowCol = SVector{2, <: Real}      # src/meta.jl:9
+const XYZ = SVector{3, <: Real}         # src/meta.jl:15
+
+"""
+    Calibration
+Mirror of the reference struct (src/meta.jl:17-25) holding numbers instead of composed closures: the maps are
+evaluated by the device library.  `c(xyz, i)`, `c(rc, i)`, `c(x)` and `rectification(c, i)` behave as in the
+reference (src/meta.jl:82-103); a `Matrix` argument ([3,M] / [2,M]) maps M points in one call.
+"""
+struct Calibration
+    f::SVector{2, Float64}               # intrinsic.linear diagonal (frow, fcol)
+    c::SVector{2, Float64}               # intrinsic.translation (crow, ccol)
+    rvecs::Matrix{Float64}               # [3,N] RotationVec per image
+    tvecs::Matrix{Float64}               # [3,N]
+    checker_size::Float64                # scale = LinearMap(I / checker_size), src/buildcalibrations.jl:4
+    k::Float64
+    files::Vector{String}
+    ctx::Context
+end
+
+(c::Calibration)(xyz::XYZ, i::Int) = SVector{2}(project(c.ctx, reshape(Float64[xyz...], 3, 1), c.f, c.c, c.k, c.rvecs[:, i], c.tvecs[:, i], c.checker_size))   # src/meta.jl:88
+(c::Calibration)(rc::RowCol, i::Int) = SVector{3}(unproject(c.ctx, reshape(Float64[rc...], 2, 1), c.f, c.c, c.k, c.rvecs[:, i], c.tvecs[:, i], c.checker_size))  # src/meta.jl:82
+(c::Calibration)(pts::Matrix{Float64}, i::Int) = size(pts, 1) == 3 ? project(c.ctx, pts, c.f, c.c, c.k, c.rvecs[:, i], c.tvecs[:, i], c.checker_size) :
+                                                                    unproject(c.ctx, pts, c.f, c.c, c.k, c.rvecs[:, i], c.tvecs[:, i], c.checker_size)
+(c::Calibration)(x) = c(x, findfirst(contains(r"extrinsic"), c.files))      # src/meta.jl:90-93
+
+rectification(c::Calibration, i) = rc -> c(rc, i)[SVector(1, 2)]            # src/meta.jl:99-103
+rectification(c::Calibration) = rectification(c, findfirst(contains(r"extrinsic"), c.files))
+
+"""
+    fit_corners(imgpointss, n_corners, checker_size, sz; files, aspect, with_distortion, inverse_samples, device)
+`fit` from already-detected corners (detection stays with OpenCV.jl or `detect_corners`): everything after
+`_detect_corners` in src/detect_fit.jl:63-72 and src/buildcalibrations.jl:12-26.  Returns `(c, ϵ)`.
+"""
+function fit_corners(imgpointss, n_corners, checker_size, sz; files = ["$i.png" for i in 1:length(imgpointss)], aspect = 1,
+                     with_distortion = true, inverse_samples = 100, device = 0)
+    @assert !isempty(imgpointss) "No checkers were detected in any of the images, perhaps try a different `n_corners`."   # src/detect_fit.jl:66
+    n1, n2 = n_corners
+    objpoints = [SVector{3, Float64}(i - 1, j - 1, 0) for i in 1:n1, j in 1:n2, _ in 1:1]          # src/detect_fit.jl:69
+    m = fit_model(sz, objpoints, imgpointss, n_corners, with_distortion, aspect; device)
+    N, P = length(imgpointss), n1 * n2
+    c = Calibration(SVector(m.frow, m.fcol), SVector(m.crow, m.ccol), reduce(hcat, m.Rs), reduce(hcat, m.ts), Float64(checker_size),
+                    m.k, collect(String, files), Context(device))
+    obj = Float64[(p - 1) % n1 * (d == 1) + (p - 1) ÷ n1 * (d == 2) for d in 1:3, p in 1:P] .* checker_size   # src/buildcalibrations.jl:15
+    img = Array{Float64}(undef, 2, P, N)
+    for (i, mm) in enumerate(imgpointss), (p, rc) in enumerate(vec(mm))
+        img[1, p, i] = rc[1]; img[2, p, i] = rc[2]
+    end
+    inv_pts = rand(2, inverse_samples, N) .* (Float64[sz...] .- 1) .+ 1                                   # src/buildcalibrations.jl:54
+    ϵ = calculate_errors(c.ctx, n_corners, obj, img, c.f, c.c, c.k, c.rvecs, c.tvecs, checker_size, inv_pts)
+    return c, ϵ
+end
+
+"""
+    fit(files, n_corners, checker_size; aspect, with_distortion, inverse_samples, detector)
+src/buildcalibrations.jl:12-26 with corner detection on the device (`detector(file) -> (gray::Matrix{UInt8})` loads an
+image; images without a full board are skipped like the reference's `missing`, src/detect_fit.jl:65).
+"""
+function fit(files, n_corners, checker_size; aspect = 1, with_distortion = true, inverse_samples = 100, device = 0, load_gray)
+    ctx = Context(device)
+    found = Tuple{String, Any}[]
+    sz = nothing
+    for file in unique(files)
+        gray = load_gray(file)
+        sz === nothing && (sz = size(gray))                         # size(FileIO.load(first(files))), src/detect_fit.jl:64
+        corners = detect_corners(ctx, gray, n_corners)
+        ismissing(corners) || push!(found, (file, [SVector(rc...) for rc in corners]))
+    end
+    return fit_corners(last.(found), n_corners, checker_size, sz; files = first.(found), aspect, with_distortion, inverse_samples, device)
 end
 
 end # module

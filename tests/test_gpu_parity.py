@@ -743,3 +743,25 @@ def test_many_image_maps_match_per_image_calls_and_oracle():
             assert np.abs(rc[i] - orc.map_forward(xyz, f, c, k, rv[i], tv[i], 2.5)).max() < 1e-9
             assert np.abs(back[i] - orc.map_inverse(rc[i], f, c, k, rv[i], tv[i], 2.5)).max() < 1e-8
         assert np.abs(back - xyz[None]).max() < 1e-8          # round trip on the board plane
+
+
+def test_cached_contexts_are_released_at_thread_exit():
+    """ccal_calibrate keeps one context per host thread (stream, ~25 device buffers, launch graph); a thread that ends
+    must give them back (thread_local guard in csrc/ccal_api.hip), or a pool of short-lived worker threads leaks."""
+    import threading
+
+    import torch
+    wl = syn.named_workload("REF", n_images=12)
+    free = []
+
+    def work():
+        m = fit_model(wl.image_size, wl.obj, list(wl.img), wl.n_corners, True, 1.0)
+        assert 0.05 < m.rms < 0.2
+    for _ in range(6):
+        t = threading.Thread(target=work)
+        t.start()
+        t.join()
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info(0)[0])
+    # the first thread pays for one-time runtime allocations; after that nothing may pile up
+    assert free[-1] >= free[1] - (4 << 20), free
