@@ -50,10 +50,10 @@ CCAL_ACC_HD void acc_split(double x, int &j, int64_t &lo, int64_t &hi, int &flag
     if (bits < 0) { lo = -lo; hi = -hi; }
 }
 
-// Sum over replicas of one limb, kept as two partial sums in binary64: a == (a >> 32) * 2^32 + (a & 0xffffffff)
-// for two's-complement a, both halves convert exactly (one v_cvt each on the device) and their sums over at
-// most 64 replicas stay far below 2^53, so the partial sums are exact integers -- without 64-bit integer
-// arithmetic, which gfx950 would have to emulate with two 32-bit instructions per operation.
+// One limb's total over the replicas (added as int64 by the reader: at most 1024 adds of 52-bit payloads, no
+// overflow) as two binary64 halves: a == (a >> 32) * 2^32 + (a & 0xffffffff) for two's-complement a, both halves
+// convert exactly (one v_cvt each on the device).  From here on the decode is floating point: no 64-bit integer
+// carry chain, which gfx950 would have to emulate with two 32-bit instructions per operation.
 struct AccPart { double hi, lo; };
 CCAL_ACC_HD void acc_part_add(AccPart &p, int64_t a) {
     p.hi += (double)(int32_t)(a >> 32);

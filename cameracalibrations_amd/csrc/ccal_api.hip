@@ -556,7 +556,7 @@ int ccal_init_extrinsics(ccal_ctx *c) {
 }
 
 // ---- A6-A9: global LM ------------------------------------------------------------------
-// (trials << 32) | done, written to pinned host memory by every k_lm_solve that advances the state
+// (trials << 32) | done, written to pinned host memory by workgroup 0 of every k_lm_trial launch that advances the state
 static unsigned long long *progress_word(ccal_ctx *c) { return reinterpret_cast<unsigned long long *>(c->h_flags + 32); }
 
 // Wait until the device reports `done` or `target_trials` executed trials.  Spinning on the

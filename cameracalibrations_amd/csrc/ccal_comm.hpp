@@ -1,7 +1,7 @@
 // ccal_comm.hpp -- native RCCL all-reduce for the image-sharded fit.
 //
 // The reduced intrinsic system (16 condensed rows of 68 doubles) is summed across GPUs with
-// ncclAllReduce on the launch stream, between k_lm_reduce and the next k_lm_trial: one tiny,
+// ncclAllReduce on the launch stream, between k_lm_row and the next k_lm_trial: one tiny,
 // latency-bound collective per LM trial.  (The default transport is the direct row exchange of
 // ccal_p2p.hpp; this one stays for nodes where peer mapping is unavailable.)  RCCL is resolved at run time (dlopen of librccl.so.1), so
 // the single-GPU library has no link-time dependency on it; inside a PyTorch process the

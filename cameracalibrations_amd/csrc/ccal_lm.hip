@@ -179,12 +179,11 @@ __device__ __forceinline__ void gj9_steps(double (&a)[9], double &b, double &dia
 // trace, per-trial kinds, counters, the reported relative step.
 template <bool BOOK>
 __device__ __forceinline__ void lm_advance_wave(LmState *__restrict__ st, const double *__restrict__ rs,
-                                                const double *__restrict__ sS, TraceRec *trace, const int lane) {
+                                                const double *__restrict__ sS, TraceRec *trace, const int lane, const int k) {
     // ---- one burst of LDS reads ----
     const int mode = st->mode;
     const int lam_lg0 = st->lambda_lg10;
     const int lg_part = st->lg_partials, iters0 = st->iters, max_iter = st->max_iter, trials0 = st->trials;
-    const int par0 = st->parity;
     const double prev_err = st->prev_err, eps = st->eps, aspect = st->aspect;
     const double err = rs[RED_ERR], r_dnum = rs[RED_DNUM], r_dden = rs[RED_DDEN], r_bad = rs[RED_BAD];
     const int la = lane < 9 ? lane : 8;
@@ -256,6 +255,10 @@ __device__ __forceinline__ void lm_advance_wave(LmState *__restrict__ st, const 
         st->n_bad = (int)r_bad;
     }
     st->trials = trials0 + 1;
+    // Trial k - 1 wrote its point's per-image blocks into buffer (k - 1) & 1.  Unless that point was a rejected
+    // candidate it is the accepted point now; after a rejection the accepted point's blocks are still where they
+    // were (the other buffer: an evaluating sweep never writes the buffer it reads).
+    if (!reject) st->parity = (k - 1) & 1;
     if (is_init) {
         if (BOOK) {
             st->sweeps = sweeps0 + 1;
@@ -280,7 +283,6 @@ __device__ __forceinline__ void lm_advance_wave(LmState *__restrict__ st, const 
         st->lambda_lg10 = lam_lg;
         st->iters = iters0 + 1;
         if (lane < 9) st->intr_prev[lane] = icl;
-        st->parity = par0 ^ 1;
         st->prev_err = err;
         if (BOOK) {
             st->rel_step = rel;
@@ -343,29 +345,37 @@ static_assert(ACC_ROW % 2 == 0, "replicas are read as 16-byte pairs");
 // Reading the exact accumulators (ccal_acc.hpp) of one trial: thread t < 170 owns the 16-byte pair t of
 // every replica; all loads are issued before anything waits on memory (one round trip), the replicas are
 // added as split integer sums (no overflow for any grid size) and left in LDS for acc_row_decode().
-struct AccRegs { AccPart p0, p1; };
+struct AccRegs { longlong2 v[8]; };                // the first eight replicas' pair, requested before anything waits
 
+// issue only: no arithmetic between these loads and the other loads of the prologue
 __device__ __forceinline__ void acc_read_issue(const long long *__restrict__ acc, int R, int tid, AccRegs &q) {
-    q.p0.hi = q.p0.lo = q.p1.hi = q.p1.lo = 0.0;
+    const longlong2 *src = reinterpret_cast<const longlong2 *>(acc) + (tid < ACC_PAIRS ? tid : 0);
+#pragma unroll
+    for (int r = 0; r < 8; r++) q.v[r] = (tid < ACC_PAIRS && r < R) ? src[(size_t)r * ACC_PAIRS] : make_longlong2(0, 0);
+}
+
+// Replica sums -> LDS.  The replicas are added as 64-bit integers (a limb holds 52 payload bits and an address
+// receives at most grid / R adds, the grid is capped at 1024 workgroups: the sum over all replicas stays below
+// 2^62), then split ONCE into the two exactly representable halves acc_decode() takes.
+__device__ __forceinline__ void acc_read_stage(const long long *__restrict__ acc, int R, AccPart *s_acc, int tid, const AccRegs &q) {
     if (tid >= ACC_PAIRS) return;
+    long long t0 = 0, t1 = 0;
+#pragma unroll
+    for (int r = 0; r < 8; r++) { t0 += q.v[r].x; t1 += q.v[r].y; }
     const longlong2 *src = reinterpret_cast<const longlong2 *>(acc) + tid;
-    for (int r0 = 0; r0 < R; r0 += 8) {
+    for (int r0 = 8; r0 < R; r0 += 8) {             // more than eight replicas (very large grids only)
         longlong2 v[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) v[r] = (r0 + r < R) ? src[(size_t)(r0 + r) * ACC_PAIRS] : make_longlong2(0, 0);
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            acc_part_add(q.p0, v[r].x);
-            acc_part_add(q.p1, v[r].y);
-        }
+        for (int r = 0; r < 8; r++) { t0 += v[r].x; t1 += v[r].y; }
     }
-}
-
-__device__ __forceinline__ void acc_read_stage(AccPart *s_acc, int tid, const AccRegs &q) {
-    if (tid < ACC_PAIRS) {
-        s_acc[2 * tid] = q.p0;
-        s_acc[2 * tid + 1] = q.p1;
-    }
+    AccPart p0, p1;
+    p0.hi = p0.lo = p1.hi = p1.lo = 0.0;
+    acc_part_add(p0, t0);
+    acc_part_add(p1, t1);
+    s_acc[2 * tid] = p0;
+    s_acc[2 * tid + 1] = p1;
 }
 
 // column `col` of the staged sums -> double (threads 0..67, after a barrier).  The pad column carries the
@@ -494,6 +504,22 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
 #ifdef CCAL_STAMPS
     asm volatile("" ::"s"(N), "s"(A.st));        // the kernel arguments have arrived
     STAMP(13);
+#ifdef CCAL_STAMPS_MEM
+    // diagnostic of the diagnostic build: three dependent single-word round trips at kernel start -- a word of the
+    // read-only corner stream, a word of the accumulators (last touched by memory-side atomics), a word of the
+    // previous state (last written by workgroup 0's plain stores) -- to see which kind of line is slow after a boundary
+    {
+        const float w0 = __builtin_nontemporal_load(A.img + (size_t)blockIdx.x * 64 + (tid & 63));
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(w0));
+        STAMP(14);
+        const long long w1 = A.acc[(size_t)((A.k + 2) % 3) * A.R * ACC_ROW + (tid & 63)];
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(w1));
+        STAMP(15);
+        const double w2 = reinterpret_cast<const double *>(A.st + ((A.k - 1) & 1))[tid & 63];
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(w2));
+        STAMP(20);
+    }
+#endif
 #endif
     // A workgroup sweeps the image groups g = blockIdx.x, blockIdx.x + gridDim.x, ... (four images each, one per
     // wave): the grid is capped at what the chip holds resident, so that the prologue above the loop -- state,
@@ -516,18 +542,20 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         if (A.row_in != nullptr) { if (tid < NRED) row_v = A.row_in[tid]; }
         else acc_read_issue(A.acc + (size_t)((A.k + 2) % 3) * acc_buf, A.R, tid, q);
     }
-    double h0a = 0.0, h1a = 0.0, h0b = 0.0, h1b = 0.0;   // block words lane (a) and 64 + lane (b) of parity 0 / 1
+    // block words lane (ha) and 64 + lane (hb) of this image.  Trial k - 1 wrote buffer (k - 1) & 1; unless its point
+    // was a rejected candidate (rare) that is the accepted point's block, so it is requested before the state is known
+    double ha = 0.0, hb = 0.0;
     const float2 *img2 = reinterpret_cast<const float2 *>(A.img) + (size_t)ii * P;
     const int pc0 = lane < P ? lane : P - 1;
     float2 uv = make_float2(0.f, 0.f);
     float m0 = 0.f, m1 = 0.f, m2 = 0.f;
     if (!A.final_only) {
         if (A.first) {
-            h0b = (lane >= BLK_EXT - 64 && lane < BLK_EXT - 64 + 6) ? A.ext0[(size_t)ii * A.ext0_stride + lane - (BLK_EXT - 64)] : 0.0;
+            hb = (lane >= BLK_EXT - 64 && lane < BLK_EXT - 64 + 6) ? A.ext0[(size_t)ii * A.ext0_stride + lane - (BLK_EXT - 64)] : 0.0;
         } else {
-            const double *b0p = A.blk + (size_t)ii * BLK, *b1p = A.blk + ((size_t)N + ii) * BLK;
-            h0a = b0p[lane]; h1a = b1p[lane];
-            h0b = b0p[64 + lane]; h1b = b1p[64 + lane];
+            const double *bp = A.blk + ((size_t)((A.k - 1) & 1) * N + ii) * BLK;
+            ha = bp[lane];
+            hb = bp[64 + lane];
         }
         uv = img2[pc0];                         // coalesced 8 B per lane
         m0 = A.obj[3 * pc0]; m1 = A.obj[3 * pc0 + 1]; m2 = A.obj[3 * pc0 + 2];
@@ -536,6 +564,18 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     }
     int oa, ob;                                 // (a, b) of the packed S0 entry this lane assembles
     tri_decode(lane < 45 ? lane : 0, oa, ob);
+    // does the reduced-system entry this lane will assemble belong to free parameters only?  (lanes 0..44: S0(oa, ob);
+    // 45..53: dA(a); 54..62: gs(a); 63: the error).  From the flag-word mask in the kernel arguments, worked out here
+    // in the shadow of the first loads.
+    bool keep;
+    {
+        unsigned int mbits = 0;
+#pragma unroll
+        for (int a = 0; a < NINTR; a++) mbits |= (A.init.mask[a] != 0 ? 1u : 0u) << a;
+        const int ka = lane < RED_DA ? oa : (lane < RED_ERR ? (lane - RED_DA) % NINTR : 0);
+        const int kb = lane < RED_DA ? ob : ka;
+        keep = lane >= RED_ERR || (((mbits >> ka) & (mbits >> kb) & 1u) != 0);
+    }
 
     // ---- 1. the state of this trial, S_k, in LDS (every workgroup computes the same bits) ----
     unsigned int seq = 0;
@@ -552,7 +592,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
             if (tid < NRED) s_rs[tid] = row_v;
             if (tid < RED_DA) { s_S[oa * SROW + ob] = row_v; s_S[ob * SROW + oa] = row_v; }
         } else {
-            acc_read_stage(s_acc, tid, q);
+            acc_read_stage(A.acc + (size_t)((A.k + 2) % 3) * acc_buf, A.R, s_acc, tid, q);
         }
         __syncthreads();
         STAMP(11);
@@ -588,8 +628,8 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
             }
         STAMP(12);
         if (wave == 0) {
-            if (blockIdx.x == 0) lm_advance_wave<true>(&ls, s_rs, s_S, A.trace, lane);
-            else lm_advance_wave<false>(&ls, s_rs, s_S, nullptr, lane);
+            if (blockIdx.x == 0) lm_advance_wave<true>(&ls, s_rs, s_S, A.trace, lane, A.k);
+            else lm_advance_wave<false>(&ls, s_rs, s_S, nullptr, lane, A.k);
         }
         __syncthreads();
     }
@@ -616,19 +656,20 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     if (ls.done || A.final_only) return;
 
     const int mode = ls.mode;
-    const int par = ls.parity;
-    const int cand = (mode == MODE_EVAL) ? 1 - par : par;   // buffer this sweep evaluates / writes
+    const int par = ls.parity;                  // buffer holding the accepted point's blocks
+    const int cand = A.k & 1;                   // buffer this sweep writes (never the one an evaluating sweep reads)
+    if (!A.first && par != ((A.k - 1) & 1)) {
+        // the previous trial's candidate was rejected: the accepted point's block is in the other buffer
+        const double *bp = A.blk + ((size_t)par * N + ii) * BLK;
+        ha = bp[lane];
+        hb = bp[64 + lane];
+    }
 
     double *W = s_wave + wave * TILE_D;
     double *Gs = W + W_G, *Hs = W + W_HEAD, *Ys = W + W_Y;
     double *red = s_red + wave * NRED;
 
     const double aspect = ls.aspect, lam_next = ls.lam_next;
-    // does the reduced-system entry this lane will assemble belong to free parameters only?
-    // lanes 0..44: S0(oa, ob); 45..53: dA(a); 54..62: gs(a); 63: the error
-    const int ka = lane < RED_DA ? oa : (lane < RED_ERR ? (lane - RED_DA) % NINTR : 0);
-    const int kb = lane < RED_DA ? ob : ka;
-    const bool keep = lane >= RED_ERR || (ls.mask[ka] != 0 && ls.mask[kb] != 0);
     double in[NINTR];                             // the intrinsics this sweep evaluates: candidate, or (INIT / RESCHUR) accepted
     {
         const double *src = (mode == MODE_EVAL) ? ls.intr_cand : ls.intr_prev;
@@ -646,7 +687,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     // ---- 2. block head of the accepted point -> wave-uniform registers ----
     // lane j holds block word j (hsel) and word 64 + j (hselb); uniform values are pulled out with
     // v_readlane, no LDS staging of the block
-    const double hsel = par ? h1a : h0a, hselb = par ? h1b : h0b;
+    const double hsel = ha, hselb = hb;
     double e6[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) e6[k] = bcast(hselb, BLK_EXT - 64 + k);
@@ -819,10 +860,11 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     ii = active ? img_i : N - 1;
     img2 = reinterpret_cast<const float2 *>(A.img) + (size_t)ii * P;
     if (A.first) {
-        h0b = (lane >= BLK_EXT - 64 && lane < BLK_EXT - 64 + 6) ? A.ext0[(size_t)ii * A.ext0_stride + lane - (BLK_EXT - 64)] : 0.0;
+        hb = (lane >= BLK_EXT - 64 && lane < BLK_EXT - 64 + 6) ? A.ext0[(size_t)ii * A.ext0_stride + lane - (BLK_EXT - 64)] : 0.0;
     } else {
-        const double *bp = A.blk + ((size_t)par * N + ii) * BLK;     // the accepted parity is known by now
-        if (par) { h1a = bp[lane]; h1b = bp[64 + lane]; } else { h0a = bp[lane]; h0b = bp[64 + lane]; }
+        const double *bp = A.blk + ((size_t)par * N + ii) * BLK;
+        ha = bp[lane];
+        hb = bp[64 + lane];
     }
     uv = img2[pc0];
     m0 = A.obj[3 * pc0]; m1 = A.obj[3 * pc0 + 1]; m2 = A.obj[3 * pc0 + 2];
@@ -850,7 +892,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_row(const long long *__restri
     if (__hip_atomic_load(&st[(k - 1) & 1].done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
     AccRegs q;
     acc_read_issue(acc + (size_t)((k + 2) % 3) * R * ACC_ROW, R, tid, q);
-    acc_read_stage(s_acc, tid, q);
+    acc_read_stage(acc + (size_t)((k + 2) % 3) * R * ACC_ROW, R, s_acc, tid, q);
     __syncthreads();
     if (tid < NRED) out[tid] = acc_row_decode(s_acc, tid);
 }
@@ -872,7 +914,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_exchange(const long long *__r
     if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;   // a peer already timed out
     AccRegs q;
     acc_read_issue(acc + (size_t)((k + 2) % 3) * R * ACC_ROW, R, tid, q);
-    acc_read_stage(s_acc, tid, q);
+    acc_read_stage(acc + (size_t)((k + 2) % 3) * R * ACC_ROW, R, s_acc, tid, q);
     __syncthreads();
     if (tid < NRED) s_val[tid] = acc_row_decode(s_acc, tid);
     __syncthreads();
@@ -896,12 +938,12 @@ int lm_max_grid() {
     int per_cu = 0, cus = 0;
     if (const char *e = getenv("CCAL_MAX_GRID")) {
         const int v = atoi(e);
-        if (v > 0) return cached[dev] = v;
+        if (v > 0) return cached[dev] = std::min(v, 1024);
     }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lm_trial<true>, WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     (void)hipGetLastError();
-    return cached[dev] = per_cu * cus;
+    return cached[dev] = std::min(per_cu * cus, 1024);   // (1024: the accumulator replicas are summed in int64)
 }
 
 hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {

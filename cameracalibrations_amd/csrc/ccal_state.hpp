@@ -4,8 +4,9 @@
 //   obj      [3,P]      f32   board template (shared by every image)
 //   img      [2,P,N]    f32   observed corners; the only O(N*P) stream: 8 B per corner-residual
 //   ext0     [N][8]     f64   initial rvec,tvec (+2 pad) per image (a solve can be re-run from it)
-//   blk      [2][N][128] f64   per-image state, double-buffered: parity p holds the last ACCEPTED
-//                             point ("prev"), 1-p the candidate being evaluated.  Per image (1 KB):
+//   blk      [2][N][128] f64   per-image state, double-buffered: trial k writes buffer k & 1; `parity` names the
+//                             buffer of the last ACCEPTED point (an evaluating sweep reads it and writes the
+//                             other one, so a rejected candidate leaves it intact).  Per image (1 KB):
 //                             rvec,tvec | U = C_l^-1 [B^T | h] for the lambda the next step uses
 //                             (back-substitution is then one 6x9 mat-vec) | pd flag
 //   acc      [3][R][5][68] i64  the reduced intrinsic system of one trial, summed EXACTLY: every workgroup adds
@@ -65,12 +66,12 @@ constexpr int MAX_KINDS = 64;
 
 struct LmState {
     // ---- header: the first HOST_WORDS 8-byte words are mirrored into pinned host memory by the
-    //      k_lm_solve that terminates the solve ----
+    //      k_lm_trial launch that terminates the solve ----
     int32_t mode;          // what the NEXT sweep does
     int32_t done;
-    int32_t parity;        // blk buffer holding the accepted point
+    int32_t parity;        // blk buffer holding the accepted point's blocks
     int32_t lambda_lg10;   // OpenCV lambdaLg10
-    int32_t lg_partials;   // log10(lambda) the sweep must use for its Schur partials
+    int32_t lg_partials;   // log10(lambda) the sweep must use for its Schur sums
     int32_t iters;
     int32_t max_iter;
     int32_t sweeps, reschur, rejected, trials;
@@ -82,7 +83,7 @@ struct LmState {
     double eps;
     double aspect;         // > 0 <=> CALIB_FIX_ASPECT_RATIO
     double lam_step;       // lambda of the step being evaluated (back-substitution)
-    double lam_next;       // lambda for the Schur partials of this sweep
+    double lam_next;       // lambda for the Schur sums of this sweep
     double prev_err, rel_step;
     double intr_prev[9];
     int32_t kinds[MAX_KINDS];   // per trial: 1 + mode of the sweep it ran (0 = no-op after `done`)
@@ -90,11 +91,11 @@ struct LmState {
     double intr_cand[9], dint[9];
     int32_t mask[9];
     int32_t pad_;
-    double pow10[33];           // lambda table 10^(lg), lg = -16..16, filled by k_lm_begin
+    double pow10[33];           // lambda table 10^(lg), lg = -16..16, filled by the first launch of a solve (lm_boot)
 };
 constexpr int HOST_WORDS = 64;  // covers everything up to and including kinds[]
 
-// Everything k_lm_begin needs to (re)build LmState on the device; passed by value as a kernel
+// Everything the first launch of a solve needs to (re)build LmState on the device; passed by value as a kernel
 // argument so that a whole solve (begin + trials + read-back) is one replayable hipGraph.
 struct LmInit {
     int32_t max_iter, max_trace, P, N_local, nblocks;

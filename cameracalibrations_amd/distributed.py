@@ -117,7 +117,7 @@ def pack_reduced(parts):
 
 
 def solve_reduced(vec, lam, mask):
-    """damped Schur system of the device's k_lm_solve: -> delta_int (9), err."""
+    """damped Schur system of the device's LM advance (k_lm_trial prologue): -> delta_int (9), err."""
     A, g = vec[:81].reshape(9, 9), vec[81:90]
     SC, sg, err = vec[90:171].reshape(9, 9), vec[171:180], vec[180]
     S = A - SC

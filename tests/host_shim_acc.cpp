@@ -51,10 +51,14 @@ double shim_sum(const double *xs, int n, int R, int *flags_out) {
         acc[i % R][j] += lo;
         if (hi) acc[i % R][j + 1] += hi;
     }
+    // as the kernels read them back: replicas added as int64 (the grid is capped at 1024 workgroups, so the total
+    // number of adds per column is), then split once into the two exactly representable halves
     AccPart part[ACC_LIMBS];
     for (int j = 0; j < ACC_LIMBS; j++) {
+        int64_t t = 0;
+        for (int r = 0; r < R; r++) t += acc[r][j];
         part[j].hi = part[j].lo = 0.0;
-        for (int r = 0; r < R; r++) acc_part_add(part[j], acc[r][j]);
+        acc_part_add(part[j], t);
     }
     return acc_decode(part);
 }

@@ -71,7 +71,7 @@ def test_split_reconstructs_the_value(shim):
 def test_sum_is_exact_and_order_independent(shim, R):
     rng = np.random.default_rng(7 + R)
     for case in range(30):
-        n = int(rng.integers(1, 3000))
+        n = int(rng.integers(1, 1024))
         scale = 10.0 ** rng.integers(-25, 25)
         xs = rng.normal(size=n) * scale * 10.0 ** rng.integers(-8, 8, n)
         if case % 3 == 0:
@@ -82,20 +82,20 @@ def test_sum_is_exact_and_order_independent(shim, R):
         assert abs(Fraction(v) - ex) <= Fraction(ulp(v)) * 2 + Fraction(1, 2 ** 150)
         for _ in range(3):
             assert acc_sum(shim, rng.permutation(xs), R)[0] == v            # bit-identical in any order
-        assert abs(acc_sum(shim, xs, 1)[0] - v) <= 2 * ulp(v)               # another replica count: same exact total, the
-                                                                            # final roundings may differ by an ulp
+        assert acc_sum(shim, xs, 1)[0] == v                                 # ... and for any replica count: the decoded
+                                                                            # value is a function of the exact total
 
 
 def test_many_adds_do_not_overflow(shim):
-    # 64 replicas x 1500 adds of the largest admissible magnitude, all of one sign
-    xs = np.full(64 * 1500, 2.0 ** 108 * (2 - 2.0 ** -52))
-    v, flags = acc_sum(shim, xs, 64)
-    assert flags == (0, 0) and abs(Fraction(v) - exact(xs)) <= 2 * Fraction(ulp(v))   # total ~2^125: top limb beyond 64 bits
-    xs = -xs
-    assert acc_sum(shim, xs, 64)[0] == -v
-    # 20000 workgroups over 8 replicas: more than 2^11 adds per address in total, still exact through the split sums
+    # the sweep grid is capped at 1024 workgroups, i.e. at most 1024 adds per column over all replicas: the largest
+    # admissible magnitude, all of one sign, 1024 times (the top limb then exceeds 53 bits: rounded, not wrapped)
+    xs = np.full(1024, 2.0 ** 108 * (2 - 2.0 ** -52))
+    for R in (1, 8, 64):
+        v, flags = acc_sum(shim, xs, R)
+        assert flags == (0, 0) and abs(Fraction(v) - exact(xs)) <= 2 * Fraction(ulp(v))
+        assert acc_sum(shim, -xs, R)[0] == -v
     rng = np.random.default_rng(3)
-    xs = rng.uniform(0.5, 1.0, 12000) * 2.0 ** 40
+    xs = rng.uniform(0.5, 1.0, 1024) * 2.0 ** 40
     v, _ = acc_sum(shim, xs, 8)
     assert abs(Fraction(v) - exact(xs)) <= Fraction(ulp(v))
 

@@ -31,7 +31,7 @@ w_unit = out.get("calib_WRITE_SIZE", {}).get("k_write8", {}).get("mean")
 summary["calibration"] = {"bytes": calib_bytes, "FETCH_SIZE_units_for_read": f_unit, "WRITE_SIZE_units_for_write": w_unit,
                           "bytes_per_FETCH_unit": calib_bytes / f_unit if f_unit else None,
                           "bytes_per_WRITE_unit": calib_bytes / w_unit if w_unit else None}
-for k in ("ccal::k_lm_trial", "ccal::k_lm_reduce"):
+for k in ("ccal::k_lm_trial", "ccal::k_lm_row"):
     fs = out.get("FETCH_SIZE", {}).get(k)
     ws = out.get("WRITE_SIZE", {}).get(k)
     if fs and ws:  # noqa

@@ -11,10 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "cameracalibrations_amd", "csrc")
 BLOCK = int(os.environ.get("CCAL_STAMP_BLOCK", "7"))
-OUT = "/tmp/libccal_hip_stamps_%d.so" % BLOCK
+MEM = os.environ.get("CCAL_STAMPS_MEM", "0") == "1"
+OUT = "/tmp/libccal_hip_stamps_%d_%d.so" % (BLOCK, MEM)
 srcs = [os.path.join(CSRC, f) for f in ("ccal_lm.hip", "ccal_init.hip", "ccal_maps.hip", "ccal_comm.hip", "ccal_p2p.hip", "ccal_detect.hip", "ccal_api.hip")]
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-sched-strategy=max-ilp",
-                       "-DCCAL_STAMPS", "-DCCAL_STAMP_BLOCK=%d" % BLOCK, "-o", OUT, *srcs, "-ldl"])
+                       "-DCCAL_STAMPS", *(["-DCCAL_STAMPS_MEM"] if MEM else []), "-DCCAL_STAMP_BLOCK=%d" % BLOCK, "-o", OUT, *srcs, "-ldl"])
 from cameracalibrations_amd import _ffi as F  # noqa: E402
 F.LIB_PATH = OUT
 from cameracalibrations_amd import synthetic as syn  # noqa: E402
@@ -43,6 +44,9 @@ with Solver(0) as s:
         if rt > 0:
             print("   shader clock over this wave's lifetime: %.0f MHz (s_memtime / s_memrealtime x 100 MHz)" % (100.0 * (int(buf[10]) - int(buf[0])) / rt))
         print("   entry -> kernel arguments in SGPRs:", int(buf[13]) - int(buf[0]), "cycles")
+        if MEM:
+            print("   dependent single-word round trips after that: corner stream (read-only)", int(buf[14]) - int(buf[13]),
+                  "| accumulators (memory-side atomics)", int(buf[15]) - int(buf[14]), "| previous state (plain stores of WG 0)", int(buf[20]) - int(buf[15]))
         t = np.array(buf[:13], dtype=np.int64)
         print("   prologue: loads -> barrier", t[11] - t[0], "decode (+exchange)", t[12] - t[11], "advance+sync", t[1] - t[12])
         a = np.array(buf[16:20], dtype=np.int64)
