@@ -143,8 +143,10 @@ __device__ __forceinline__ double rcp_pos(double d) {
     return fma(y, e, y);
 }
 
-// The nine elimination steps of the 9x9 solve, rows in lanes 0..8 (lanes 9..15 mirror row 8): pivot and
-// pivot row reach the other lanes of the 16-lane row through DPP row broadcasts of lane J.
+// The nine elimination steps of the 9x9 solve, rows in lanes 0..8 (lanes 9..15 mirror row 8): pivot and pivot row
+// reach the other lanes of the 16-lane row through DPP row broadcasts of lane J.  (Skipping the steps of fixed
+// parameters -- identity rows -- behind a wave-uniform branch was measured: the nine basic blocks cost the
+// straight-line version 500 cycles at K = 8, more than the one skipped step saves.)
 template <int J>
 __device__ __forceinline__ void gj9_steps(double (&a)[9], double &b, double &diag, bool &ok, int lane, std::integral_constant<int, J>) {
     const double d = row_bcast16<J>(a[J]);          // pivot
@@ -177,7 +179,7 @@ __device__ __forceinline__ void gj9_steps(double (&a)[9], double &b, double &dia
 // its row with five wide LDS reads.  Uniform values are stored by every lane to the same LDS address; per-parameter values by lanes 0..8.
 // BOOK = true (workgroup 0 only, whose copy is persisted) also keeps the books the host reads:
 // trace, per-trial kinds, counters, the reported relative step.
-template <bool BOOK>
+template <bool BOOK, bool FINAL>
 __device__ __forceinline__ void lm_advance_wave(LmState *__restrict__ st, const double *__restrict__ rs,
                                                 const double *__restrict__ sS, TraceRec *trace, const int lane, const int k) {
     // ---- one burst of LDS reads ----
@@ -235,7 +237,10 @@ __device__ __forceinline__ void lm_advance_wave(LmState *__restrict__ st, const 
     STAMP2(1);
     bool ok = true;                                 // (per lane; lane 0's copy decides)
     double diag = 1.0;                              // this lane's own pivot, rescaled along with its row
-    gj9_steps(a, b, diag, ok, lane, std::integral_constant<int, 0>());
+    // the terminating (prologue-only) launch of a solve has nothing to overlap the decisions with: it solves only when
+    // a step will actually be taken (i.e. the solve goes on in another batch of launches)
+    const bool will_step = !(reject || (nonfinite && (is_init || accept)) || (accept && (iters0 + 1 >= max_iter || small || lg_part != lam_lg)));
+    if (!FINAL || will_step) gj9_steps(a, b, diag, ok, lane, std::integral_constant<int, 0>());
     ok = (__ballot(ok) & 1ull) != 0;
     STAMP2(2);
     // x_i = b_i / a_ii, one correction step on the quotient
@@ -484,7 +489,9 @@ __device__ void lm_boot(LmState *ls, const LmInit &init, const double *intr0, in
 #ifndef CCAL_TRIAL_MIN_WAVES
 #define CCAL_TRIAL_MIN_WAVES 2   /* two workgroups per CU (LDS-limited anyway): keep the register file share of two waves per SIMD */
 #endif
-template <bool XCHG>
+// LOOP = the grid is smaller than the number of image groups (a workgroup sweeps several groups); the one-group form
+// is compiled separately because the loop's carried state costs it 75 VGPRs and a few hundred cycles.
+template <bool XCHG, bool LOOP>
 __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(const TrialArgs A) {
     __shared__ __attribute__((aligned(16))) double s_wave[WAVES * TILE_D];
     __shared__ __attribute__((aligned(16))) double s_red[WAVES * NRED];
@@ -628,8 +635,9 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
             }
         STAMP(12);
         if (wave == 0) {
-            if (blockIdx.x == 0) lm_advance_wave<true>(&ls, s_rs, s_S, A.trace, lane, A.k);
-            else lm_advance_wave<false>(&ls, s_rs, s_S, nullptr, lane, A.k);
+            if (A.final_only) lm_advance_wave<true, true>(&ls, s_rs, s_S, A.trace, lane, A.k);     // (one workgroup: it keeps the books)
+            else if (blockIdx.x == 0) lm_advance_wave<true, false>(&ls, s_rs, s_S, A.trace, lane, A.k);
+            else lm_advance_wave<false, false>(&ls, s_rs, s_S, nullptr, lane, A.k);
         }
         __syncthreads();
     }
@@ -683,7 +691,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
 
     for (bool first_group = true;; first_group = false) {
     const int g_next = g + (int)gridDim.x;
-    const bool last_group = g_next >= n_groups;   // workgroup-uniform
+    const bool last_group = !LOOP || g_next >= n_groups;   // workgroup-uniform
     // ---- 2. block head of the accepted point -> wave-uniform registers ----
     // lane j holds block word j (hsel) and word 64 + j (hselb); uniform values are pulled out with
     // v_readlane, no LDS staging of the block
@@ -940,7 +948,7 @@ int lm_max_grid() {
         const int v = atoi(e);
         if (v > 0) return cached[dev] = std::min(v, 1024);
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lm_trial<true>, WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lm_trial<true, true>, WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     (void)hipGetLastError();
     return cached[dev] = std::min(per_cu * cus, 1024);   // (1024: the accumulator replicas are summed in int64)
@@ -958,19 +966,20 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     memset(&a.p2p, 0, sizeof a.p2p);
     // sweep grid: one workgroup per four images up to what the chip keeps resident; beyond that the workgroups loop
     const int grid = t.final_only ? 1 : std::min(lm_sweep_blocks(t.N), lm_max_grid());
+    const bool loop = grid < lm_sweep_blocks(t.N);
+    auto launch = [&](auto kernel) {
+        if (t.ev_start != nullptr && t.ev_stop != nullptr)   // events bound to this dispatch: its own begin / end
+            hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(WAVES * 64), 0, stream, t.ev_start, t.ev_stop, 0, a);
+        else
+            hipLaunchKernelGGL(kernel, dim3(grid), dim3(WAVES * 64), 0, stream, a);
+    };
     if (t.p2p != nullptr) {
         a.p2p = *t.p2p;
         a.xchg_fused = t.xchg_fused;
-        if (t.ev_start != nullptr && t.ev_stop != nullptr)
-            hipExtLaunchKernelGGL(k_lm_trial<true>, dim3(grid), dim3(WAVES * 64), 0, stream, t.ev_start, t.ev_stop, 0, a);
-        else
-            hipLaunchKernelGGL(k_lm_trial<true>, dim3(grid), dim3(WAVES * 64), 0, stream, a);
-        return hipGetLastError();
+        if (loop) launch(k_lm_trial<true, true>); else launch(k_lm_trial<true, false>);
+    } else {
+        if (loop) launch(k_lm_trial<false, true>); else launch(k_lm_trial<false, false>);
     }
-    if (t.ev_start != nullptr && t.ev_stop != nullptr)   // events bound to this dispatch: its own begin / end
-        hipExtLaunchKernelGGL(k_lm_trial<false>, dim3(grid), dim3(WAVES * 64), 0, stream, t.ev_start, t.ev_stop, 0, a);
-    else
-        hipLaunchKernelGGL(k_lm_trial<false>, dim3(grid), dim3(WAVES * 64), 0, stream, a);
     return hipGetLastError();
 }
 
