@@ -79,6 +79,9 @@ struct ccal_ctx {
     // grow-only device scratch + pinned, device-mapped staging of the map / metric / warp entry points
     void *d_scratch = nullptr, *h_pin = nullptr;
     size_t scratch_cap = 0;
+    void *h_stage = nullptr;           // grow-only pinned staging of mid-size transfers
+    size_t stage_cap = 0;
+    unsigned long long pin_seq = 0;    // sequence number of the zero-copy path's completion word
     std::vector<double> h_rt_stage;
     // pinned host mirrors
     LmState *h_st = nullptr;
@@ -179,6 +182,7 @@ int ccal_create(int device, ccal_ctx **out) {
     HIPCHK(hipMalloc(&c->d_intr_scratch, sizeof(double) * 9));
     HIPCHK(hipMalloc(&c->d_trace, sizeof(TraceRec) * c->max_trace));
     HIPCHK(hipHostMalloc(&c->h_pin, 64 * 1024, hipHostMallocMapped));
+    memset(c->h_pin, 0, 64 * 1024);
     HIPCHK(hipHostMalloc(&c->h_st, sizeof(LmState), hipHostMallocDefault));
     HIPCHK(hipHostMalloc(&c->h_flags, sizeof(int) * 64, hipHostMallocDefault));   // flags | intr staging | progress
     const char *b = getenv("CCAL_LM_BATCH");
@@ -201,6 +205,7 @@ void ccal_destroy(ccal_ctx *c) {
     (void)hipFree(c->d_trace); (void)hipFree(c->d_intr0); (void)hipFree(c->d_intr_scratch);
     if (c->g_first) (void)hipGraphExecDestroy(c->g_first);
     (void)hipHostFree(c->h_st); (void)hipHostFree(c->h_flags); (void)hipHostFree(c->h_pin); (void)hipFree(c->d_scratch);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto &e : c->ev) (void)hipEventDestroy(e);
     delete c->comm;
     delete c->p2p;
@@ -1070,7 +1075,7 @@ int ccal_calibrate_multi(const float *obj, const float *img, int32_t P, int32_t 
 // call.  Small calls (the reference's `c(rc, i)` for one point, src/meta.jl:82,88) do not even copy: input,
 // poses and output sit in one pinned, device-mapped staging block that the kernel reads and writes over PCIe,
 // so such a call is a memcpy, one launch and one stream synchronisation.
-static constexpr size_t PIN_BYTES = 64 * 1024;
+static constexpr size_t PIN_BYTES = 64 * 1024 - 64;   // (the last 64 bytes of the staging block hold the completion word)
 
 static int scratch_need(ccal_ctx *c, size_t bytes) {
     if (bytes <= c->scratch_cap) return CCAL_OK;
@@ -1085,6 +1090,21 @@ static int scratch_need(ccal_ctx *c, size_t bytes) {
 }
 
 static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// grow-only pinned host staging for mid-size transfers (caller buffers are pageable: copied through here, the
+// DMA itself always runs pinned <-> device); beyond STAGE_MAX the runtime's own pageable path is used
+static constexpr size_t STAGE_MAX = 16u << 20;
+static int stage_need(ccal_ctx *c, size_t bytes) {
+    if (bytes <= c->stage_cap) return CCAL_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr;
+    c->stage_cap = 0;
+    const size_t cap = bytes + bytes / 2 + 4096;
+    HIPCHK(hipHostMalloc(&c->h_stage, cap, hipHostMallocDefault));
+    c->stage_cap = cap;
+    return CCAL_OK;
+}
 
 // in [in_w, M, N] (or one [3, M] template when !per_image) -> out [out_w, M, N], image n through pose n
 static int map_many(ccal_ctx *c, const double *in, int32_t M, int32_t N, bool per_image, const double f[2], const double cc[2],
@@ -1113,17 +1133,46 @@ static int map_many(ccal_ctx *c, const double *in, int32_t M, int32_t N, bool pe
     double *h_rt = small ? d_rt : (c->h_rt_stage.resize(n_rt), c->h_rt_stage.data());
     for (int i = 0; i < N; i++)
         for (int a = 0; a < 3; a++) { h_rt[(size_t)6 * i + a] = rvecs[(size_t)3 * i + a]; h_rt[(size_t)6 * i + 3 + a] = tvecs[(size_t)3 * i + a]; }
+    const bool staged = !small && b_rt + b_in + b_out <= STAGE_MAX;
+    char *hs = nullptr;
+    if (staged) {
+        const int rc = stage_need(c, b_rt + b_in + b_out);
+        if (rc) return rc;
+        hs = static_cast<char *>(c->h_stage);
+    }
     if (small) {
         memcpy(d_in, in, 8 * n_in);
+    } else if (staged) {
+        memcpy(hs, h_rt, 8 * n_rt);
+        memcpy(hs + b_rt, in, 8 * n_in);
+        HIPCHK(hipMemcpyAsync(d_rt, hs, b_rt + 8 * n_in, hipMemcpyHostToDevice, c->stream));   // poses + points: one DMA
     } else {
         HIPCHK(hipMemcpyAsync(d_rt, h_rt, 8 * n_rt, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(d_in, in, 8 * n_in, hipMemcpyHostToDevice, c->stream));
     }
     if (forward) HIPCHK(launch_map_forward(c->stream, d_in, per_image ? (long long)3 * M : 0ll, d_out, M, N, mi, d_rt));
     else HIPCHK(launch_map_inverse(c->stream, d_in, d_out, M, N, mi, d_rt));
-    if (!small) HIPCHK(hipMemcpyAsync(out, d_out, 8 * n_out, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (small) memcpy(out, d_out, 8 * n_out);
+    if (!small) {
+        HIPCHK(hipMemcpyAsync(staged ? static_cast<void *>(hs + b_rt + b_in) : static_cast<void *>(out), d_out, 8 * n_out,
+                              hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (staged) memcpy(out, hs + b_rt + b_in, 8 * n_out);
+        return CCAL_OK;
+    }
+    // zero-copy path: a one-thread kernel behind the map kernel raises a sequence number in pinned memory; spin on it
+    // (a blocking stream synchronisation costs tens to hundreds of microseconds of wake-up latency per call)
+    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(static_cast<char *>(c->h_pin) + PIN_BYTES);
+    const unsigned long long want = ++c->pin_seq;
+    HIPCHK(launch_signal(c->stream, const_cast<unsigned long long *>(flag), want));
+    const double t_end = now_s() + 2e-3;
+    bool seen = false;
+    for (long spins = 0; !seen; spins++) {
+        seen = *flag == want;
+        if (!seen && (spins & 255) == 255 && now_s() > t_end) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) HIPCHK(hipStreamSynchronize(c->stream));
+    memcpy(out, d_out, 8 * n_out);
     return CCAL_OK;
 }
 

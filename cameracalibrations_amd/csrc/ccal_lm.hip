@@ -819,6 +819,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         } else {
             v = err_i;                                    // lane 63
         }
+        STAMP(21);
         // this wave's sums over its images (wave-private LDS; fixed parameters leave zero rows / columns, dA = 0, g = 0)
         const double vv = (active && keep) ? v : 0.0;
         red[lane] = first_group ? vv : red[lane] + vv;
@@ -829,7 +830,9 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         }
     }
     if (last_group) {
+    STAMP(22);
     __syncthreads();
+    STAMP(23);
     if (tid < NRED) {
         double s = s_red[tid];
 #pragma unroll

@@ -173,6 +173,17 @@ hipError_t launch_rectify(hipStream_t stream, const uint8_t *img, int rows, int 
     return hipGetLastError();
 }
 
+// completion marker for the zero-copy path: stream order puts it behind the map kernel, whose stores to pinned
+// host memory have left the device when it ends; the host spins on this word instead of paying the wake-up
+// latency of hipStreamSynchronize
+__global__ void k_signal(unsigned long long *flag, unsigned long long value) {
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_signal(hipStream_t stream, unsigned long long *flag, unsigned long long value) {
+    hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, stream, flag, value);
+    return hipGetLastError();
+}
+
 hipError_t launch_map_forward(hipStream_t stream, const double *xyz, long long xyz_stride, double *rc, int M, int N,
                               const MapIntr &in, const double *rt) {
     hipLaunchKernelGGL(k_map_forward, dim3((M + 255) / 256, N), dim3(256), 0, stream, xyz, xyz_stride, rc, M, in, rt);

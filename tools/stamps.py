@@ -43,6 +43,8 @@ with Solver(0) as s:
         rt = int(buf[31]) - int(buf[30])
         if rt > 0:
             print("   shader clock over this wave's lifetime: %.0f MHz (s_memtime / s_memrealtime x 100 MHz)" % (100.0 * (int(buf[10]) - int(buf[0])) / rt))
+        print("   outputs phase: Schur dots", int(buf[21]) - int(buf[8]), "| sums to LDS", int(buf[22]) - int(buf[21]), "| barrier", int(buf[23]) - int(buf[22]),
+              "| workgroup sum + split + atomics issued", int(buf[9]) - int(buf[23]))
         print("   entry -> kernel arguments in SGPRs:", int(buf[13]) - int(buf[0]), "cycles")
         if MEM:
             print("   dependent single-word round trips after that: corner stream (read-only)", int(buf[14]) - int(buf[13]),
