@@ -504,7 +504,7 @@ def main():
             "lm": lm_block(r, rt, tight_ms),
             "init": {"intrinsics_ms": 1e3 * rf["t_init_intr_s"], "extrinsics_ms": 1e3 * rf["t_init_extr_s"], "full_fit_ms": fit_ms},
             "roofline": roofline_block(N, P, K, sweep_us, n_timed, sweep_us_b2b, 1e3 * ev_s,
-                                       "ccal::k_lm_trial<%s, false>" % ("true" if world > 1 else "false")),
+                                       "ccal::k_lm_trial<%s, false, 1>" % ("true" if world > 1 else "false")),
             "parity": "device == oracle (CPU restatement of OpenCV 4.10 from the published algorithm) in tests/; no run of OpenCV "
                       "pins the trajectory (iters-to-tol) -- DESIGN.md section 2",
         }
@@ -549,8 +549,8 @@ def main():
                              "config": config_block(wl5, "full", 4, my5.shape[0], wl5.n_images, world, comm5, CRITERIA, True),
                              "lm": lm_block(r5),
                              "roofline": roofline_block(my5.shape[0], wl5.n_points, free_intrinsics(wl5.flags), us5, n5, b2b5,
-                                                        1e3 * ev5, "ccal::k_lm_trial<%s, %s>" % ("true" if world > 1 else "false",
-                                                                                              "true" if my5.shape[0] > 2048 else "false"))}
+                                                        1e3 * ev5, "ccal::k_lm_trial<%s, %s, 1>" % ("true" if world > 1 else "false",
+                                                                                                 "true" if my5.shape[0] > 2048 else "false"))}
             s5.close()
             del s5
         except Exception as exc:      # noqa: BLE001

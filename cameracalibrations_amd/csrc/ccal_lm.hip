@@ -491,7 +491,9 @@ __device__ void lm_boot(LmState *ls, const LmInit &init, const double *intr0, in
 #endif
 // LOOP = the grid is smaller than the number of image groups (a workgroup sweeps several groups); the one-group form
 // is compiled separately because the loop's carried state costs it 75 VGPRs and a few hundred cycles.
-template <bool XCHG, bool LOOP>
+// KIND: 0 = first launch of a solve (builds S_0 instead of advancing), 1 = a later trial, 2 = the terminating
+// prologue-only launch.  Separate instantiations: each kind drops the other kinds' paths (and their registers).
+template <bool XCHG, bool LOOP, int KIND>
 __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(const TrialArgs A) {
     __shared__ __attribute__((aligned(16))) double s_wave[WAVES * TILE_D];
     __shared__ __attribute__((aligned(16))) double s_red[WAVES * NRED];
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     const LmState *prev = A.st + ((A.k - 1) & 1);
     double sw = 0.0, row_v = 0.0;
     AccRegs q;
-    if (!A.first) {
+    if ((KIND != 0)) {
         if (tid < STATE_WORDS) sw = reinterpret_cast<const double *>(prev)[tid];
         if (A.row_in != nullptr) { if (tid < NRED) row_v = A.row_in[tid]; }
         else acc_read_issue(A.acc + (size_t)((A.k + 2) % 3) * acc_buf, A.R, tid, q);
@@ -556,8 +558,8 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     const int pc0 = lane < P ? lane : P - 1;
     float2 uv = make_float2(0.f, 0.f);
     float m0 = 0.f, m1 = 0.f, m2 = 0.f;
-    if (!A.final_only) {
-        if (A.first) {
+    if ((KIND != 2)) {
+        if ((KIND == 0)) {
             hb = (lane >= BLK_EXT - 64 && lane < BLK_EXT - 64 + 6) ? A.ext0[(size_t)ii * A.ext0_stride + lane - (BLK_EXT - 64)] : 0.0;
         } else {
             const double *bp = A.blk + ((size_t)((A.k - 1) & 1) * N + ii) * BLK;
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     // ---- 1. the state of this trial, S_k, in LDS (every workgroup computes the same bits) ----
     unsigned int seq = 0;
     if constexpr (XCHG) seq = __hip_atomic_load(A.p2p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (A.first) {
+    if ((KIND == 0)) {
         lm_boot(&ls, A.init, A.intr0, tid);
         // no other workgroup of this launch reads the sequence number; the launches after it see seq + 1
         if constexpr (XCHG)
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
             if (blockIdx.x == 0) {
                 LmState *cur = A.st + (A.k & 1);
                 if (tid < STATE_WORDS) reinterpret_cast<double *>(cur)[tid] = reinterpret_cast<const double *>(&ls)[tid];
-                if (A.final_only) acc_clear(A.acc, A.R, ACC_BUFS, tid);
+                if ((KIND == 2)) acc_clear(A.acc, A.R, ACC_BUFS, tid);
             }
             return;
         }
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
             }
         STAMP(12);
         if (wave == 0) {
-            if (A.final_only) lm_advance_wave<true, true>(&ls, s_rs, s_S, A.trace, lane, A.k);     // (one workgroup: it keeps the books)
+            if ((KIND == 2)) lm_advance_wave<true, true>(&ls, s_rs, s_S, A.trace, lane, A.k);     // (one workgroup: it keeps the books)
             else if (blockIdx.x == 0) lm_advance_wave<true, false>(&ls, s_rs, s_S, A.trace, lane, A.k);
             else lm_advance_wave<false, false>(&ls, s_rs, s_S, nullptr, lane, A.k);
         }
@@ -659,14 +661,14 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         }
         // the terminating launch of a finished solve leaves every accumulator cleared (its own input was
         // consumed before the barrier above); an unfinished one keeps its input for the trial that follows
-        if (A.final_only && ls.done) acc_clear(A.acc, A.R, ACC_BUFS, tid);
+        if ((KIND == 2) && ls.done) acc_clear(A.acc, A.R, ACC_BUFS, tid);
     }
-    if (ls.done || A.final_only) return;
+    if (ls.done || (KIND == 2)) return;
 
     const int mode = ls.mode;
     const int par = ls.parity;                  // buffer holding the accepted point's blocks
     const int cand = A.k & 1;                   // buffer this sweep writes (never the one an evaluating sweep reads)
-    if (!A.first && par != ((A.k - 1) & 1)) {
+    if ((KIND != 0) && par != ((A.k - 1) & 1)) {
         // the previous trial's candidate was rejected: the accepted point's block is in the other buffer
         const double *bp = A.blk + ((size_t)par * N + ii) * BLK;
         ha = bp[lane];
@@ -870,7 +872,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     active = img_i < N;
     ii = active ? img_i : N - 1;
     img2 = reinterpret_cast<const float2 *>(A.img) + (size_t)ii * P;
-    if (A.first) {
+    if ((KIND == 0)) {
         hb = (lane >= BLK_EXT - 64 && lane < BLK_EXT - 64 + 6) ? A.ext0[(size_t)ii * A.ext0_stride + lane - (BLK_EXT - 64)] : 0.0;
     } else {
         const double *bp = A.blk + ((size_t)par * N + ii) * BLK;
@@ -951,7 +953,7 @@ int lm_max_grid() {
         const int v = atoi(e);
         if (v > 0) return cached[dev] = std::min(v, 1024);
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lm_trial<true, true>, WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lm_trial<true, true, 1>, WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     (void)hipGetLastError();
     return cached[dev] = std::min(per_cu * cus, 1024);   // (1024: the accumulator replicas are summed in int64)
@@ -969,19 +971,25 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     memset(&a.p2p, 0, sizeof a.p2p);
     // sweep grid: one workgroup per four images up to what the chip keeps resident; beyond that the workgroups loop
     const int grid = t.final_only ? 1 : std::min(lm_sweep_blocks(t.N), lm_max_grid());
-    const bool loop = grid < lm_sweep_blocks(t.N);
+    const bool loop = !t.final_only && grid < lm_sweep_blocks(t.N);
     auto launch = [&](auto kernel) {
         if (t.ev_start != nullptr && t.ev_stop != nullptr)   // events bound to this dispatch: its own begin / end
             hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(WAVES * 64), 0, stream, t.ev_start, t.ev_stop, 0, a);
         else
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(WAVES * 64), 0, stream, a);
     };
+    auto pick = [&](auto xchg) {
+        constexpr bool X = decltype(xchg)::value;
+        if (t.final_only) launch(k_lm_trial<X, false, 2>);
+        else if (t.first) { if (loop) launch(k_lm_trial<X, true, 0>); else launch(k_lm_trial<X, false, 0>); }
+        else { if (loop) launch(k_lm_trial<X, true, 1>); else launch(k_lm_trial<X, false, 1>); }
+    };
     if (t.p2p != nullptr) {
         a.p2p = *t.p2p;
         a.xchg_fused = t.xchg_fused;
-        if (loop) launch(k_lm_trial<true, true>); else launch(k_lm_trial<true, false>);
+        pick(std::true_type());
     } else {
-        if (loop) launch(k_lm_trial<false, true>); else launch(k_lm_trial<false, false>);
+        pick(std::false_type());
     }
     return hipGetLastError();
 }
