@@ -439,14 +439,15 @@ def test_sharded_fit_two_ranks_on_one_gpu():
     assert np.abs(rv - base["rvecs"]).max() < 1e-10 and np.abs(tv - base["tvecs"]).max() < 1e-9
 
 
-@pytest.mark.parametrize("world,n_total", [(2, 41), (3, 41), (2, 2650)])
+@pytest.mark.parametrize("world,n_total", [(2, 41), (3, 41), (2, 2650), (2, 4400)])
 def test_sharded_fit_p2p_exchange_on_one_gpu(world, n_total):
     """Same joint fit through the direct exchange (ccal_p2p_export / ccal_p2p_connect): the ranks'
     inboxes are fine-grained device allocations mapped into each other's process through HIP IPC,
     rows travel as {epoch | payload} words written by the peers' kernels, every solve is one
     hipGraph per rank.  Ranks share the test box's single GPU (the fabric hop is the driver's
     multi-GPU run); 3 ranks cover uneven shards and the rank-ordered sum; 2650 images put more than
-    320 workgroups on each rank, i.e. the separate exchange kernel instead of the fused prologue."""
+    320 workgroups on each rank, i.e. the separate exchange kernel instead of the fused prologue; 4400 images
+    (550 image groups per rank) exceed the resident grid, i.e. the looping sweep instantiation."""
     import socket
 
     import torch.multiprocessing as mp
