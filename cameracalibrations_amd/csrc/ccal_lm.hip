@@ -738,7 +738,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         }
         const double M[3] = {(double)m0, (double)m1, (double)m2};
         double mu[NCOL], mv[NCOL];
-        point_rows_K(M, (double)uv.x, (double)uv.y, R, K, e6 + 3, in, aspect, mu, mv);
+        point_rows_K(M, (double)uv.x, (double)uv.y, R, K, e6 + 3, in, aspect, mu, mv, valid ? 1.0 : 0.0);
         STAMP(4);
 #ifdef CCAL_HALF_TILE
         // half-size tile (occupancy): lanes 0..31 stage their rows, Gram of those corners, then lanes 32..63
@@ -746,14 +746,14 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         for (int h = 0; h < 2; h++) {
             const int n_h = min(32, P - c0 - 32 * h);
             if (n_h > 0) {
-                if ((lane >> 5) == h) tile_store_rows(W, lane, mu, mv, valid);
+                if ((lane >> 5) == h) tile_store_rows_masked(W, lane, mu, mv);
                 wave_lds_sync();
                 tile_gram(W, lane, n_h, acc0, acc1);
                 wave_lds_sync();
             }
         }
 #else
-        tile_store_rows(W, lane, mu, mv, valid);
+        tile_store_rows_masked(W, lane, mu, mv);
         wave_lds_sync();
         STAMP(5);
         tile_gram(W, lane, min(64, P - c0), acc0, acc1);

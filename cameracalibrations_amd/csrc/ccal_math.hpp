@@ -202,12 +202,15 @@ CCAL_HD void rodrigues_RK(const double r[3], double R[9], double K[9]) {
     K[6] = b * xz - a * r[1];   K[7] = b * yz + a * r[0];   K[8] = sc + b * zz;
 }
 
-// point_rows with the rotation derivative in K form (same columns as point_rows)
+// point_rows with the rotation derivative in K form (same columns as point_rows).  `vm` = 1 for a real
+// corner, 0 for a padding lane: it rides on multiplications the rows make anyway (every Jacobian column carries a
+// factor fx or fy), so that a padding lane's two rows come out as exact zeros without 32 value selects.
 CCAL_HD void point_rows_K(const double M[3], double u_obs, double v_obs, const double R[9],
                           const double K[9], const double t[3], const double in[NINTR],
-                          double aspect, double mu[NCOL], double mv[NCOL]) {
+                          double aspect, double mu[NCOL], double mv[NCOL], double vm = 1.0) {
     const double fx = in[0], fy = in[1], cx = in[2], cy = in[3];
     const double k1 = in[4], k2 = in[5], p1 = in[6], p2 = in[7], k3 = in[8];
+    const double fxv = fx * vm, fyv = fy * vm;
     const double Xr = R[0] * M[0] + R[1] * M[1] + R[2] * M[2];
     const double Yr = R[3] * M[0] + R[4] * M[1] + R[5] * M[2];
     const double Zr = R[6] * M[0] + R[7] * M[1] + R[8] * M[2];
@@ -221,14 +224,15 @@ CCAL_HD void point_rows_K(const double M[3], double u_obs, double v_obs, const d
     const double yd = y * cd + p1 * a3 + p2 * a1;
     const double dcd_dr2 = k1 + 2.0 * k2 * r2 + 3.0 * k3 * r4;
 
-    mu[COL_E] = fx * xd + cx - u_obs;
-    mv[COL_E] = fy * yd + cy - v_obs;
-    if (aspect > 0.0) { mu[6] = 0.0; mu[7] = xd * aspect; }
-    else              { mu[6] = xd;  mu[7] = 0.0; }
-    mv[6] = 0.0; mv[7] = yd;
-    mu[8] = 1.0; mu[9] = 0.0; mv[8] = 0.0; mv[9] = 1.0;
-    mu[10] = fx * x * r2; mu[11] = fx * x * r4; mu[12] = fx * a1; mu[13] = fx * a2; mu[14] = fx * x * r6;
-    mv[10] = fy * y * r2; mv[11] = fy * y * r4; mv[12] = fy * a3; mv[13] = fy * a1; mv[14] = fy * y * r6;
+    mu[COL_E] = (fx * xd + cx - u_obs) * vm;
+    mv[COL_E] = (fy * yd + cy - v_obs) * vm;
+    const double xdv = xd * vm;
+    if (aspect > 0.0) { mu[6] = 0.0; mu[7] = xdv * aspect; }
+    else              { mu[6] = xdv; mu[7] = 0.0; }
+    mv[6] = 0.0; mv[7] = yd * vm;
+    mu[8] = vm; mu[9] = 0.0; mv[8] = 0.0; mv[9] = vm;
+    mu[10] = fxv * x * r2; mu[11] = fxv * x * r4; mu[12] = fxv * a1; mu[13] = fxv * a2; mu[14] = fxv * x * r6;
+    mv[10] = fyv * y * r2; mv[11] = fyv * y * r4; mv[12] = fyv * a3; mv[13] = fyv * a1; mv[14] = fyv * y * r6;
 
 #pragma unroll
     for (int j = 0; j < 6; j++) {
@@ -245,8 +249,8 @@ CCAL_HD void point_rows_K(const double M[3], double u_obs, double v_obs, const d
         const double dr2 = 2.0 * x * dx + 2.0 * y * dy;
         const double dcd = dcd_dr2 * dr2;
         const double da1 = 2.0 * (x * dy + y * dx);
-        mu[j] = fx * (cd * dx + x * dcd + p1 * da1 + p2 * (dr2 + 4.0 * x * dx));
-        mv[j] = fy * (cd * dy + y * dcd + p1 * (dr2 + 4.0 * y * dy) + p2 * da1);
+        mu[j] = fxv * (cd * dx + x * dcd + p1 * da1 + p2 * (dr2 + 4.0 * x * dx));
+        mv[j] = fyv * (cd * dy + y * dcd + p1 * (dr2 + 4.0 * y * dy) + p2 * da1);
     }
 }
 

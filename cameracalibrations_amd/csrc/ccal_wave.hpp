@@ -88,6 +88,16 @@ __device__ __forceinline__ void tile_store_rows(double *tile, int lane, const do
     }
 }
 
+// The same without selects, for rows that are already exact zeros in padding lanes (point_rows_K's vm).
+__device__ __forceinline__ void tile_store_rows_masked(double *tile, int lane, const double mu[16], const double mv[16]) {
+    double2 *dst = reinterpret_cast<double2 *>(tile + (lane & (TILE_PTS - 1)) * TILE_LD);
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        dst[c] = make_double2(mu[2 * c], mu[2 * c + 1]);
+        dst[8 + c] = make_double2(mv[2 * c], mv[2 * c + 1]);
+    }
+}
+
 // Wave-private LDS hand-off: the DS unit executes one wave's instructions in order, so a
 // ds_write followed by a ds_read of the SAME wave needs no s_barrier; this only stops the
 // compiler from moving LDS accesses of different lanes' addresses across the hand-off.
