@@ -25,7 +25,7 @@
 using namespace ccal;
 
 #ifdef CCAL_STAMPS
-namespace ccal { hipError_t debug_read_stamps(unsigned long long *out); hipError_t debug_read_init_stamps(unsigned long long *out); hipError_t debug_read_init_blocks(unsigned int *out); }
+namespace ccal { hipError_t debug_read_stamps(unsigned long long *out); hipError_t debug_read_wg_times(unsigned long long *out); hipError_t debug_read_init_stamps(unsigned long long *out); hipError_t debug_read_init_blocks(unsigned int *out); }
 #endif
 
 // direct xGMI exchange: fused into the prologue of k_lm_trial while a rank has at most this many
@@ -1344,6 +1344,11 @@ int ccal_debug_init_stamps(unsigned long long *out) {
 int ccal_debug_init_blocks(unsigned int *out) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(ccal::debug_read_init_blocks(out));
+    return CCAL_OK;
+}
+int ccal_debug_wg_times(unsigned long long *out) {
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(ccal::debug_read_wg_times(out));
     return CCAL_OK;
 }
 int ccal_debug_stamps(unsigned long long *out) {

@@ -60,6 +60,16 @@ constexpr int WAVES = 4;             // images per workgroup
 #define CCAL_STAMP_BLOCK 7
 #endif
 __device__ unsigned long long g_stamps[32];
+// every workgroup's timeline on the chip-wide 100 MHz counter: entry, prologue done, exit, and where it ran
+__device__ unsigned long long g_wg_times[1024 * 4];
+#define WG_TIME(i)                                                                            \
+    do {                                                                                      \
+        if (KIND == 1 && threadIdx.x == 0 && blockIdx.x < 1024) {                             \
+            unsigned long long t_;                                                            \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");     \
+            g_wg_times[blockIdx.x * 4 + (i)] = t_;                                            \
+        }                                                                                     \
+    } while (0)
 #define STAMP(i)                                                                              \
     do {                                                                                      \
         if (blockIdx.x == CCAL_STAMP_BLOCK && tid == 0) {                                                    \
@@ -92,6 +102,7 @@ __device__ unsigned long long g_stamps[32];
 #define STAMP(i) do { } while (0)
 #define STAMP2(i) do { } while (0)
 #define STAMP_RT(i) do { } while (0)
+#define WG_TIME(i) do { } while (0)
 #endif
 
 // packed-lower decode o -> (a, b), a >= b, for o < 55 (no memory table: arithmetic in the
@@ -405,6 +416,9 @@ __device__ __forceinline__ void acc_add(long long *__restrict__ dst, int col, do
     int j, flag;
     int64_t lo, hi;
     acc_split(v, j, lo, hi, flag);
+#ifdef CCAL_EXP_NO_ACC             // timing experiment only (no sums at all)
+    if (col >= 0) return;
+#endif
 #ifdef CCAL_EXP_STORE_NOT_ATOMIC   // timing experiment only (wrong sums): what the atomics cost against plain stores
     dst[j * NRED + col] = lo;
     dst[(j + 1) * NRED + col] = hi;
@@ -507,6 +521,16 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     const int tid = threadIdx.x;
     STAMP(0);
     STAMP_RT(30);
+    WG_TIME(0);
+#ifdef CCAL_STAMPS
+    if (KIND == 1 && threadIdx.x == 0 && blockIdx.x < 1024) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_wg_times[blockIdx.x * 4 + 3] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = A.N, P = A.P;
@@ -644,6 +668,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         __syncthreads();
     }
     STAMP(1);
+    WG_TIME(1);
     if (blockIdx.x == 0) {
         LmState *cur = A.st + (A.k & 1);
         if (tid < STATE_WORDS) reinterpret_cast<double *>(cur)[tid] = reinterpret_cast<const double *>(&ls)[tid];
@@ -840,6 +865,8 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
 #pragma unroll
         for (int w = 1; w < WAVES; w++) s += s_red[w * NRED + tid];   // fixed order inside the workgroup
         // ... and exact, order-independent across workgroups: limbs added with integer atomics
+        // (replica = workgroup index mod R: with R = 8 and round-robin dispatch that is the workgroup's XCD, so one
+        //  replica is only ever added to through one L2 -- choosing it from HW_REG_XCC_ID instead measured the same)
         acc_add(A.acc + ((size_t)(A.k % 3) * A.R + (blockIdx.x & (A.R - 1))) * ACC_ROW, tid, s);
     }
     }
@@ -861,8 +888,12 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     wave_lds_sync();
     if (active) {
         double *bo = A.blk + ((size_t)cand * N + ii) * BLK;
+#ifdef CCAL_EXP_NO_BLOCK           // timing experiment only (wrong results): what the block stores add to the launch boundary
+        if (A.k > 1000) { bo[lane] = Hs[lane]; bo[64 + lane] = Hs[64 + lane]; }
+#else
         bo[lane] = Hs[lane];
         bo[64 + lane] = Hs[64 + lane];
+#endif
     }
     if (last_group) break;
     g = g_next;
@@ -885,11 +916,15 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     }
     STAMP(10);
     STAMP_RT(31);
+    WG_TIME(2);
 }
 
 #ifdef CCAL_STAMPS
 hipError_t debug_read_stamps(unsigned long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32);
+}
+hipError_t debug_read_wg_times(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_times), sizeof(unsigned long long) * 4096);
 }
 #endif
 
