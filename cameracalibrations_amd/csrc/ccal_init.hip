@@ -616,6 +616,9 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
     int lambdaLg10 = -3, iters = 0, state = 1;   // 1 STARTED, 2 CALC_J, 3 CHECK_ERR
     int n_j = 0, n_e = 0;
     (void)n_j; (void)n_e;
+#ifdef CCAL_STAMPS
+    unsigned long long t_step = 0, t_jac = 0, t_err = 0;
+#endif
     double errNorm = 0.0, prevErrNorm = 0.0;
     const double *in = pts.in;
     for (int guard = 0; ok && guard < 20 * 24; guard++) {
@@ -641,6 +644,9 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
                 state = 2;
             }
         }
+#ifdef CCAL_STAMPS
+        const unsigned long long ts0 = memtime_now();
+#endif
         if (do_step) {
             // CvLevMarq::step: diag *= 1 + lambda; solve; param = prev - delta
             double A[21], d[6];
@@ -658,9 +664,18 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
             for (int k = 0; k < 6; k++) rt[k] = prev[k] - (pd ? d[k] : 0.0);
             rodrigues_RK(rt, R, K);
         }
+#ifdef CCAL_STAMPS
+        const unsigned long long ts1 = memtime_now();
+        if (do_step) t_step += ts1 - ts0;
+#endif
         if (state == 2) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_tile, s_G, JtJ, JtErr)); n_j++; }
         else { errNorm = sqrt(view_error(obj, img_i, P, lane, rt, R, in)); n_e++; }
+#ifdef CCAL_STAMPS
+        const unsigned long long ts2 = memtime_now();
+        if (state == 2) t_jac += ts2 - ts1; else t_err += ts2 - ts1;
+#endif
     }
+    ICOUNT(8, t_step); ICOUNT(9, t_jac); ICOUNT(10, t_err);
     ISTAMP(3);
     ICOUNT(4, n_j); ICOUNT(5, n_e); ICOUNT(6, iters);
 #ifdef CCAL_STAMPS
