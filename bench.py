@@ -13,6 +13,8 @@ Extra blocks of the same JSON line (never `value`):
   "c5"            BASELINE.json configs[4] shape, 10000 x 15x10 corners, full k1..k3,p1,p2 model: whole on the
                   one GPU at N = 1, sharded 10000 / N images per rank at N > 1 (1250 per rank at 8).
   "maps"          RowCol <-> XYZ maps and the four RMS error metrics on C3's 54 000 corners (N = 1).
+  "detect"        corner detection (the step before the fit, reference src/detect_fit.jl:5-21) on the reference's six
+                  example images and on two synthetic boards of its test generator (N = 1).
 
 One step = one complete global LM solve from the closed-form initial values (rows A4/A5
 run once on the device before timing and are reported separately, as SURVEY.md 8d defines the metric), observed
@@ -194,6 +196,48 @@ def maps_block(wl, rf, with_cpu=True, reps=20):
         out["cpu_errors_corners_per_s"] = N * P / (time.perf_counter() - t0)
         out["cpu"] = f"oracle (plain C, one thread), {n} images for the maps, all {N} for the metrics"
         out["errors_vs_cpu_max_abs"] = float(max(abs(eo[kk] - e[kk]) for kk in eo))
+    return out
+
+
+def detect_block(with_cpu=True, reps=10):
+    """Corner detection through the C ABI (host image in, RowCol corners out): the reference's six example images
+    (tests/golden/example_png, expected corners from its test/example/corners.json) and two boards of its synthetic
+    generator (test/runtests.jl:6-43, restated in oracle/detect_oracle.py)."""
+    from PIL import Image
+
+    from cameracalibrations_amd.detect import detect_corners
+    from oracle import detect_oracle as D
+    ex = json.load(open(os.path.join(ROOT, "tests", "golden", "example_corners.json")))
+    nc = tuple(ex["n_corners"])
+    cases = [(np.ascontiguousarray(np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "example_png", f)))), nc,
+              np.array(t, dtype=np.float64)) for f, t in zip(ex["files"], ex["corners"])]
+    for w, h, ratio in ((13, 14, 95), (7, 10, 60)):
+        xys, img = D.generate_checkerboard((w, h), ratio)
+        cases.append((np.ascontiguousarray(img.astype(np.uint8)), (w, h), xys))
+    out = {"images": len(cases), "pixels": int(sum(im.size for im, _, _ in cases)), "stat": "median over %d passes over the images" % reps,
+           "what": "ccal_detect_corners per image, host buffer in, corners out (PCIe inclusive)"}
+    worst = 0.0
+    for im, n, truth in cases:                    # warm-up + the reference's bar (every corner within 1 px)
+        res = detect_corners(im, n)
+        if res is None:
+            raise RuntimeError("board not found")
+        worst = max(worst, float(np.linalg.norm(res.transpose(1, 0, 2).reshape(-1, 2) - truth, axis=1).max()))
+    out["max_corner_error_px"] = worst
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for im, n, _ in cases:
+            detect_corners(im, n)
+        ts.append(time.perf_counter() - t0)
+    out["images_per_s"] = len(cases) / float(np.median(ts))
+    out["pixels_per_s"] = out["pixels"] / float(np.median(ts))
+    if with_cpu:
+        t0 = time.perf_counter()
+        ro = [D.detect_corners(im, n) for im, n, _ in cases[:3]]
+        out["cpu_images_per_s"] = 3 / (time.perf_counter() - t0)
+        out["cpu"] = "oracle/detect_oracle.py (numpy, one thread), first 3 images"
+        out["vs_cpu_max_abs_px"] = max(float(np.abs(detect_corners(im, n).transpose(1, 0, 2).reshape(-1, 2) - r).max())
+                                       for (im, n, _), r in zip(cases[:3], ro))
     return out
 
 
@@ -423,7 +467,7 @@ def main():
     ap.add_argument("--workload", default="C3", help="headline workload: C1, C3, C5, REF (cameracalibrations_amd/synthetic.py)")
     ap.add_argument("--images", type=int, default=None, help="override the workload's image count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the weak_scaling / c5 / maps blocks")
+    ap.add_argument("--no-extras", action="store_true", help="skip the weak_scaling / c5 / maps / detect blocks")
     ap.add_argument("--allreduce", default=os.environ.get("CCAL_ALLREDUCE", "p2p"), choices=["p2p", "rccl", "torch"],
                     help="N > 1: 'p2p' = direct xGMI row exchange kernels (self-tested at start-up, else every rank falls back "
                          "together), 'rccl' = ncclAllReduce called by the library itself, 'torch' = torch.distributed hook")
@@ -569,6 +613,10 @@ def main():
             out["maps"] = maps_block(wl, rf, with_cpu=not args.no_cpu_baseline)
         except Exception as exc:      # noqa: BLE001
             out["maps"] = {"error": str(exc)}
+        try:
+            out["detect"] = detect_block(with_cpu=not args.no_cpu_baseline)
+        except Exception as exc:      # noqa: BLE001
+            out["detect"] = {"error": str(exc)}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

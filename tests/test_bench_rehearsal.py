@@ -41,6 +41,9 @@ def test_bench_single_gpu_line():
     assert m["points"] == 54000 and m["forward_points_per_s"] > 1e6 and m["inverse_points_per_s"] > 1e6
     # (the Julia maps carry ONE radial coefficient: C3's k2, p1, p2 are dropped there, so this is not the fit's 0.137 px)
     assert m["errors"]["reprojection"] < 5.0 and m["single_point_call_us"] < 500
+    # corner detection on the reference's example images: its own bar (every corner within 1 px of corners.json)
+    t = d["detect"]
+    assert t["images"] == 8 and t["max_corner_error_px"] < 1.0 and t["images_per_s"] > 10
 
 
 @pytest.mark.gpu
