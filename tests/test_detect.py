@@ -115,6 +115,26 @@ def test_gpu_full_calibration_from_files():
 
 
 @pytest.mark.gpu
+def test_gpu_fit_drops_images_without_a_board_and_duplicates(tmp_path):
+    """src/buildcalibrations.jl:14 (`unique(files)`) and src/detect_fit.jl:65 (`skipmissing`): a file listed twice counts
+    once, an image in which no board is found is dropped -- the fit is the one of the remaining files."""
+    from PIL import Image
+
+    import cameracalibrations_amd as cc
+    files = sorted(os.path.join(PNG, f) for f in os.listdir(PNG) if f.endswith(".png"))
+    blank = str(tmp_path / "blank.png")
+    Image.fromarray(np.full((375, 500), 128, dtype=np.uint8)).save(blank)
+    noise = str(tmp_path / "noise.png")
+    Image.fromarray(np.random.default_rng(1).integers(0, 256, (375, 500), dtype=np.uint8)).save(noise)
+    c0, e0 = cc.fit(files, (5, 8), 1, rng=np.random.default_rng(3))
+    c1, e1 = cc.fit([files[0], blank] + files + [noise, files[2]], (5, 8), 1, rng=np.random.default_rng(3))
+    assert e1["n"] == 6 and list(c1.files) == list(c0.files)
+    assert np.array_equal(c1.f, c0.f) and np.array_equal(c1.c, c0.c) and c1.k == c0.k
+    assert np.array_equal(c1.rvecs, c0.rvecs) and np.array_equal(c1.tvecs, c0.tvecs)
+    assert e1["reprojection"] == e0["reprojection"]
+
+
+@pytest.mark.gpu
 def test_gpu_detection_threaded():
     """runtests.jl:45-51: the detection wrapper is used under Threads.@threads -- one device context
     per host thread, identical results."""
