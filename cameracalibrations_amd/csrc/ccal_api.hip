@@ -531,11 +531,19 @@ int ccal_init_intrinsics(ccal_ctx *c) {
     const double t0 = now_s();
     HIPCHK(launch_init_homography(c->stream, c->d_obj, c->d_img, c->d_H, c->d_foc_partials, c->N, c->P, c->width,
                                   c->height));
-    HIPCHK(launch_init_focal_reduce(c->stream, c->d_foc_partials, c->d_foc_red, c->N));
-    int rc = run_allreduce(c, c->d_foc_red, NFOC);
-    if (rc) return rc;
     const double aspect = (c->flags & CCAL_FIX_ASPECT_RATIO) ? c->aspect : 0.0;
-    HIPCHK(launch_init_focal_solve(c->stream, c->d_foc_red, c->d_intr0, c->d_fail, c->width, c->height, aspect));
+    int rc = CCAL_OK;
+    const bool exchange = via_p2p(c) || (c->comm && c->comm->ready()) || c->ar_fn;
+    if (!exchange) {
+        // this GPU holds every image: sums and the 2x2 solve in one launch
+        HIPCHK(launch_init_focal_reduce_solve(c->stream, c->d_foc_partials, c->d_foc_red, c->N, c->d_intr0, c->d_fail, c->width,
+                                              c->height, aspect));
+    } else {
+        HIPCHK(launch_init_focal_reduce(c->stream, c->d_foc_partials, c->d_foc_red, c->N));
+        rc = run_allreduce(c, c->d_foc_red, NFOC);
+        if (rc) return rc;
+        HIPCHK(launch_init_focal_solve(c->stream, c->d_foc_red, c->d_intr0, c->d_fail, c->width, c->height, aspect));
+    }
     if (!c->defer_sync && (rc = finish_init(c, true, false)) != CCAL_OK) return rc;
     c->have_intr = true;
     c->have_result = false;

@@ -92,6 +92,25 @@ struct NormPoints {              // A5: centred template xy -> normalised (undis
     }
 };
 
+// A point source with this lane's first-pass point (index min(lane, P - 1): what every pass over the points asks for
+// first) kept in registers: one image is a dozen to several dozen passes over the same 54 points, and every pass
+// otherwise starts with a round trip to memory (and, for NormPoints, two divisions).  Same values, same results.
+template <class Inner>
+struct CachedPoints {
+    Inner inner;
+    int cidx;
+    double cMx, cMy, cmx, cmy;
+    __device__ __forceinline__ void init(const Inner &src, int lane, int P) {
+        inner = src;
+        cidx = lane < P ? lane : P - 1;
+        inner.get(cidx, cMx, cMy, cmx, cmy);
+    }
+    __device__ __forceinline__ void get(int p, double &Mx, double &My, double &mx, double &my) const {
+        if (p == cidx) { Mx = cMx; My = cMy; mx = cmx; my = cmy; }
+        else inner.get(p, Mx, My, mx, my);
+    }
+};
+
 // ---------------------------------------------------------------------------------------
 // homography residual (+ Jacobian rows) of one correspondence, h[8] = 1
 // [OCV-K HomographyRefineCallback::compute]
@@ -369,7 +388,9 @@ __global__ __launch_bounds__(64) void k_init_homography(const float *__restrict_
     __shared__ __attribute__((aligned(16))) double s_tile[TILE_D];
     __shared__ __attribute__((aligned(16))) double s_G[256];
     const int i = blockIdx.x, lane = threadIdx.x;
-    RawPoints pts{obj, reinterpret_cast<const float2 *>(img) + (size_t)i * P};
+    const RawPoints raw{obj, reinterpret_cast<const float2 *>(img) + (size_t)i * P};
+    CachedPoints<RawPoints> pts;
+    pts.init(raw, lane, P);
     double H[9];
     const bool ok = wave_homography(pts, P, lane, s_tile, s_G, H);
     if (lane < 9) H_out[(size_t)9 * i + lane] = ok ? H[lane] : 0.0;
@@ -407,27 +428,9 @@ __global__ __launch_bounds__(64) void k_init_homography(const float *__restrict_
     }
 }
 
-__global__ __launch_bounds__(1024) void k_init_focal_reduce(const double *__restrict__ foc, double *__restrict__ red,
-                                                             int N) {
-    // 128 slices x NFOC columns; slice sums are combined in a fixed order (deterministic)
-    __shared__ double part[128][NFOC];
-    const int j = threadIdx.x % NFOC, c = threadIdx.x / NFOC;
-    double s = 0.0;
-    for (int i = c; i < N; i += 128) s += foc[(size_t)NFOC * i + j];
-    part[c][j] = s;
-    __syncthreads();
-    if (threadIdx.x < NFOC) {
-        double t = 0.0;
-        for (int k = 0; k < 128; k++) t += part[k][threadIdx.x];
-        red[threadIdx.x] = t;
-    }
-}
-
-__global__ __launch_bounds__(64) void k_init_focal_solve(const double *__restrict__ red, double *__restrict__ intr0,
-                                                          int *__restrict__ fail_count, int width, int height,
-                                                          double aspect) {
-    if (threadIdx.x != 0) return;
-    // cvSolve(A, b, f, CV_NORMAL + CV_SVD): 2x2 normal equations
+// [OCV-K cvInitIntrinsicParams2D]: cvSolve(A, b, f, CV_NORMAL + CV_SVD) on the 2x2 normal equations (one thread)
+__device__ void focal_solve(const double *red, double *__restrict__ intr0, int *__restrict__ fail_count, int width, int height,
+                            double aspect) {
     double A[3] = {red[0], red[1], red[2]}, f[2] = {red[3], red[4]};
     int bad = red[5] > 0.0 ? 1 : 0;
     double ip2[2];
@@ -449,6 +452,36 @@ __global__ __launch_bounds__(64) void k_init_focal_solve(const double *__restric
     intr0[3] = !height ? 0.5 : (height - 1) * 0.5;
     for (int a = 4; a < 9; a++) intr0[a] = 0.0;
     fail_count[1] = bad;
+}
+
+// intr0 != NULL: this GPU holds every image, the solve follows in the same launch (no all-reduce in between)
+__global__ __launch_bounds__(1024) void k_init_focal_reduce(const double *__restrict__ foc, double *__restrict__ red,
+                                                             int N, double *__restrict__ intr0, int *__restrict__ fail_count,
+                                                             int width, int height, double aspect) {
+    // 128 slices x NFOC columns; slice sums are combined in a fixed order (deterministic)
+    __shared__ double part[128][NFOC];
+    __shared__ double fin[NFOC];
+    const int j = threadIdx.x % NFOC, c = threadIdx.x / NFOC;
+    double s = 0.0;
+    for (int i = c; i < N; i += 128) s += foc[(size_t)NFOC * i + j];
+    part[c][j] = s;
+    __syncthreads();
+    if (threadIdx.x < NFOC) {
+        double t = 0.0;
+        for (int k = 0; k < 128; k++) t += part[k][threadIdx.x];
+        red[threadIdx.x] = t;
+        fin[threadIdx.x] = t;
+    }
+    if (intr0 == nullptr) return;
+    __syncthreads();
+    if (threadIdx.x == 0) focal_solve(fin, intr0, fail_count, width, height, aspect);
+}
+
+__global__ __launch_bounds__(64) void k_init_focal_solve(const double *__restrict__ red, double *__restrict__ intr0,
+                                                          int *__restrict__ fail_count, int width, int height,
+                                                          double aspect) {
+    if (threadIdx.x != 0) return;
+    focal_solve(red, intr0, fail_count, width, height, aspect);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -490,14 +523,18 @@ __device__ __forceinline__ void rodrigues_inv(const double R[9], double r[3]) {
 }
 
 // residual-only / residual+Jacobian pass of the per-view LM
+struct FirstPoint { float m[3]; float2 uv; };      // this lane's point of the first pass (index min(lane, P - 1)), kept in registers
+
 __device__ double view_error(const float *obj, const float2 *img, int P, int lane, const double rt[6],
-                             const double R[9], const double in[NINTR]) {
+                             const double R[9], const double in[NINTR], const FirstPoint &fp) {
     double s = 0.0;
     for (int c0 = 0; c0 < P; c0 += 64) {
         const int p = c0 + lane;
         if (p < P) {
-            const double M[3] = {(double)obj[3 * p], (double)obj[3 * p + 1], (double)obj[3 * p + 2]};
-            const float2 uv = img[p];
+            const bool first = c0 == 0;
+            const double M[3] = {(double)(first ? fp.m[0] : obj[3 * p]), (double)(first ? fp.m[1] : obj[3 * p + 1]),
+                                 (double)(first ? fp.m[2] : obj[3 * p + 2])};
+            const float2 uv = first ? fp.uv : img[p];
             double eu, ev;
             point_residual(M, (double)uv.x, (double)uv.y, R, rt + 3, in, eu, ev);
             s += eu * eu + ev * ev;
@@ -509,14 +546,16 @@ __device__ double view_error(const float *obj, const float2 *img, int P, int lan
 // JtJ (6x6 packed), Jt e and ||e||^2 of one view through the packed 8-column MFMA Gram
 __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int lane, const double rt[6],
                                  const double R[9], const double K[9], const double in[NINTR], double *tile, double *Gs,
-                                 double JtJ[21], double JtErr[6]) {
+                                 double JtJ[21], double JtErr[6], const FirstPoint &fp) {
     d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     for (int c0 = 0; c0 < P; c0 += 64) {
         const int p = c0 + lane;
         const bool valid = p < P;
         const int pc = valid ? p : P - 1;
-        const double M[3] = {(double)obj[3 * pc], (double)obj[3 * pc + 1], (double)obj[3 * pc + 2]};
-        const float2 uv = img[pc];
+        const bool first = c0 == 0;
+        const double M[3] = {(double)(first ? fp.m[0] : obj[3 * pc]), (double)(first ? fp.m[1] : obj[3 * pc + 1]),
+                             (double)(first ? fp.m[2] : obj[3 * pc + 2])};
+        const float2 uv = first ? fp.uv : img[pc];
         double mu[NCOL], mv[NCOL];
         point_rows_K(M, (double)uv.x, (double)uv.y, R, K, rt + 3, in, 0.0, mu, mv);
         const double ru[8] = {mu[0], mu[1], mu[2], mu[3], mu[4], mu[5], mu[COL_E], 0.0};
@@ -571,7 +610,9 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
     const unsigned long long t_begin = memtime_now();
 #endif
     ISTAMP(0);
-    const bool ok = wave_homography(pts, P, lane, s_tile, s_G, H);
+    CachedPoints<NormPoints> cpts;
+    cpts.init(pts, lane, P);
+    const bool ok = wave_homography(cpts, P, lane, s_tile, s_G, H);
     ISTAMP(1);
     if (ok) {
         double h1[3] = {H[0], H[3], H[6]}, h2[3] = {H[1], H[4], H[7]}, h3[3] = {H[2], H[5], H[8]};
@@ -621,6 +662,12 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
 #endif
     double errNorm = 0.0, prevErrNorm = 0.0;
     const double *in = pts.in;
+    FirstPoint fp;
+    {
+        const int p0 = lane < P ? lane : P - 1;
+        fp.m[0] = obj[3 * p0]; fp.m[1] = obj[3 * p0 + 1]; fp.m[2] = obj[3 * p0 + 2];
+        fp.uv = img_i[p0];
+    }
     for (int guard = 0; ok && guard < 20 * 24; guard++) {
         bool do_step = false;
         if (state == 1) {
@@ -668,8 +715,8 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
         const unsigned long long ts1 = memtime_now();
         if (do_step) t_step += ts1 - ts0;
 #endif
-        if (state == 2) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_tile, s_G, JtJ, JtErr)); n_j++; }
-        else { errNorm = sqrt(view_error(obj, img_i, P, lane, rt, R, in)); n_e++; }
+        if (state == 2) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_tile, s_G, JtJ, JtErr, fp)); n_j++; }
+        else { errNorm = sqrt(view_error(obj, img_i, P, lane, rt, R, in, fp)); n_e++; }
 #ifdef CCAL_STAMPS
         const unsigned long long ts2 = memtime_now();
         if (state == 2) t_jac += ts2 - ts1; else t_err += ts2 - ts1;
@@ -701,7 +748,14 @@ hipError_t launch_init_homography(hipStream_t stream, const float *obj, const fl
     return hipGetLastError();
 }
 hipError_t launch_init_focal_reduce(hipStream_t stream, const double *foc_partials, double *foc_red, int N) {
-    hipLaunchKernelGGL(k_init_focal_reduce, dim3(1), dim3(1024), 0, stream, foc_partials, foc_red, N);
+    hipLaunchKernelGGL(k_init_focal_reduce, dim3(1), dim3(1024), 0, stream, foc_partials, foc_red, N, (double *)nullptr, (int *)nullptr,
+                       0, 0, 0.0);
+    return hipGetLastError();
+}
+hipError_t launch_init_focal_reduce_solve(hipStream_t stream, const double *foc_partials, double *foc_red, int N, double *intr0,
+                                          int *fail_count, int width, int height, double aspect) {
+    hipLaunchKernelGGL(k_init_focal_reduce, dim3(1), dim3(1024), 0, stream, foc_partials, foc_red, N, intr0, fail_count, width,
+                       height, aspect);
     return hipGetLastError();
 }
 hipError_t launch_init_focal_solve(hipStream_t stream, const double *foc_red, double *intr0, int *fail_count,

@@ -44,6 +44,8 @@ constexpr int NFOC = 8;   // doubles all-reduced for the focal least squares: At
 hipError_t launch_init_homography(hipStream_t stream, const float *obj, const float *img, double *H_out,
                                   double *foc_partials, int N, int P, int width, int height);
 hipError_t launch_init_focal_reduce(hipStream_t stream, const double *foc_partials, double *foc_red, int N);
+hipError_t launch_init_focal_reduce_solve(hipStream_t stream, const double *foc_partials, double *foc_red, int N, double *intr0,
+                                          int *fail_count, int width, int height, double aspect);
 hipError_t launch_init_focal_solve(hipStream_t stream, const double *foc_red, double *intr0, int *fail_count,
                                    int width, int height, double aspect);
 hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const float *img, const double *intr0,
