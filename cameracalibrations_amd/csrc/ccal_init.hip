@@ -158,12 +158,12 @@ __device__ void homog_normal_eq(const Pts &pts, int P, int lane, const double h[
         const double ru[8] = {Mx * ww, My * ww, ww, -Mx * ww * xi, -My * ww * xi, eu, 0.0, 0.0};
         const double rv[8] = {Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi, ev, 0.0, 0.0};
         tile8_store_rows(tile, lane, ru, rv, valid);
-        __syncthreads();
+        wave_lds_sync();      // (one wave per workgroup)
         tile8_gram(tile, lane, min(64, P - c0), acc0, acc1);
-        __syncthreads();
+        wave_lds_sync();      // (one wave per workgroup)
     }
     gram_to_lds(Gs, lane, acc0, acc1);
-    __syncthreads();
+    wave_lds_sync();      // (one wave per workgroup)
     // packed index k of parameter a inside the u-block (0-2, 6->3, 7->4) and the v-block (3-5 -> 0-2, 6->3, 7->4)
 #pragma unroll
     for (int a = 0; a < 8; a++) {
@@ -182,7 +182,7 @@ __device__ void homog_normal_eq(const Pts &pts, int P, int lane, const double h[
         v[a] = w;
     }
     S = Gs[5 * 16 + 5] + Gs[13 * 16 + 13];
-    __syncthreads();
+    wave_lds_sync();      // (one wave per workgroup)
 }
 
 // [OCV-K LMSolverImpl::run] with maxIters = 10, eps = FLT_EPSILON on the 8 free entries
@@ -302,12 +302,12 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *tile, d
         const double ru[8] = {X, Y, 1.0, -x * X, -x * Y, -x, 0.0, 0.0};
         const double rv[8] = {X, Y, 1.0, -y * X, -y * Y, -y, 0.0, 0.0};
         tile8_store_rows(tile, lane, ru, rv, valid);
-        __syncthreads();
+        wave_lds_sync();      // (one wave per workgroup)
         tile8_gram(tile, lane, min(64, P - c0), acc0, acc1);
-        __syncthreads();
+        wave_lds_sync();      // (one wave per workgroup)
     }
     gram_to_lds(Gs, lane, acc0, acc1);
-    __syncthreads();
+    wave_lds_sync();      // (one wave per workgroup)
     double A[45], trace = 0.0;
 #pragma unroll
     for (int a = 0; a < 9; a++) {
@@ -322,7 +322,7 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *tile, d
         }
         trace += A[tri(a, a)];
     }
-    __syncthreads();
+    wave_lds_sync();      // (one wave per workgroup)
     // smallest eigenvector: inverse iteration on LtL + mu I (mu keeps the factor positive
     // definite for noise-free data, where the smallest eigenvalue is 0 up to rounding)
     const double mu_shift = 1e-11 * trace;
@@ -561,12 +561,12 @@ __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int
         const double ru[8] = {mu[0], mu[1], mu[2], mu[3], mu[4], mu[5], mu[COL_E], 0.0};
         const double rv[8] = {mv[0], mv[1], mv[2], mv[3], mv[4], mv[5], mv[COL_E], 0.0};
         tile8_store_rows(tile, lane, ru, rv, valid);
-        __syncthreads();
+        wave_lds_sync();      // (one wave per workgroup)
         tile8_gram(tile, lane, min(64, P - c0), acc0, acc1);
-        __syncthreads();
+        wave_lds_sync();      // (one wave per workgroup)
     }
     gram_to_lds(Gs, lane, acc0, acc1);
-    __syncthreads();
+    wave_lds_sync();      // (one wave per workgroup)
 #pragma unroll
     for (int a = 0; a < 6; a++) {
 #pragma unroll
@@ -574,7 +574,7 @@ __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int
         JtErr[a] = Gs[a * 16 + 6] + Gs[(8 + a) * 16 + 14];
     }
     const double e2 = Gs[6 * 16 + 6] + Gs[14 * 16 + 14];
-    __syncthreads();
+    wave_lds_sync();      // (one wave per workgroup)
     return e2;
 }
 
