@@ -37,6 +37,16 @@ static __device__ __forceinline__ unsigned long long memtime_now() {
             g_init_stamps[i] = t_;                                                            \
         }                                                                                     \
     } while (0)
+#define JSUB(i)                                                                               \
+    do {                                                                                      \
+        if (blockIdx.x == 7 && threadIdx.x == 0) {                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            unsigned long long t_;                                                            \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            g_init_stamps[11 + (i)] = t_;                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+        }                                                                                     \
+    } while (0)
 #define ICOUNT(i, v) do { if (blockIdx.x == 7 && threadIdx.x == 0) g_init_stamps[i] = (unsigned long long)(v); } while (0)
 hipError_t debug_read_init_stamps(unsigned long long *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_init_stamps), sizeof(unsigned long long) * 16);
@@ -46,6 +56,7 @@ hipError_t debug_read_init_blocks(unsigned int *out) {
 }
 #else
 #define IBLK(j, v) do { } while (0)
+#define JSUB(i) do { } while (0)
 #define ISTAMP(i) do { } while (0)
 #define ICOUNT(i, v) do { } while (0)
 #endif
@@ -557,16 +568,19 @@ __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int
                              (double)(first ? fp.m[2] : obj[3 * pc + 2])};
         const float2 uv = first ? fp.uv : img[pc];
         double mu[NCOL], mv[NCOL];
-        point_rows_K(M, (double)uv.x, (double)uv.y, R, K, rt + 3, in, 0.0, mu, mv);
+        JSUB(0);
+        point_rows_K(M, (double)uv.x, (double)uv.y, R, K, rt + 3, in, 0.0, mu, mv, valid ? 1.0 : 0.0);   // padding lanes: zero rows
         const double ru[8] = {mu[0], mu[1], mu[2], mu[3], mu[4], mu[5], mu[COL_E], 0.0};
         const double rv[8] = {mv[0], mv[1], mv[2], mv[3], mv[4], mv[5], mv[COL_E], 0.0};
-        tile8_store_rows(tile, lane, ru, rv, valid);
+        tile8_store_rows(tile, lane, ru, rv, true);
         wave_lds_sync();      // (one wave per workgroup)
+        JSUB(1);
         tile8_gram(tile, lane, min(64, P - c0), acc0, acc1);
         wave_lds_sync();      // (one wave per workgroup)
     }
     gram_to_lds(Gs, lane, acc0, acc1);
     wave_lds_sync();      // (one wave per workgroup)
+    JSUB(2);
 #pragma unroll
     for (int a = 0; a < 6; a++) {
 #pragma unroll
@@ -575,6 +589,7 @@ __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int
     }
     const double e2 = Gs[6 * 16 + 6] + Gs[14 * 16 + 14];
     wave_lds_sync();      // (one wave per workgroup)
+    JSUB(3);
     return e2;
 }
 

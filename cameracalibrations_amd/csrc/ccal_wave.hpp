@@ -148,10 +148,17 @@ __device__ __forceinline__ void tile8_store_rows(double *tile, int lane, const d
 __device__ __forceinline__ void tile8_gram(const double *tile, int lane, int npts, d4 &acc0, d4 &acc1) {
     const int rd_off = (lane >> 4) * TILE8_LD + (lane & 15);   // k-step s: corners 4s .. 4s+3
     const int nsteps = (((npts + 3) >> 2) + 1) & ~1;            // rounded up to even (zero rows beyond npts)
-    for (int s = 0; s < nsteps; s += 2) {
-        const double a0 = tile[s * 4 * TILE8_LD + rd_off], a1 = tile[(s + 1) * 4 * TILE8_LD + rd_off];
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, a0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, a1, acc1, 0, 0, 0);
+    // all sixteen operands are requested before the first MFMA waits for one (every one of the 64 corner rows of
+    // the tile is written, zeros beyond npts): one LDS latency per pass instead of one per pair of k-steps
+    double a[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) a[s] = tile[s * 4 * TILE8_LD + rd_off];
+#pragma unroll
+    for (int s = 0; s < 16; s += 2) {
+        if (s < nsteps) {                                       // wave-uniform
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], a[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s + 1], a[s + 1], acc1, 0, 0, 0);
+        }
     }
 }
 
