@@ -101,6 +101,7 @@ SIGNATURES = {
     "ccal_detect_corners": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
                                       C.c_int32, _dp, C.POINTER(C.c_int32), _dp]),
     "ccal_debug_image_grams": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "ccal_debug_acc_sum": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32, _dp]),
     "ccal_get_init": (C.c_int, [C.c_void_p, _dp, _dp]),
     "ccal_time_sweep": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
 }

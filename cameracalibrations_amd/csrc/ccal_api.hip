@@ -1343,6 +1343,22 @@ int ccal_time_sweep(ccal_ctx *c, int32_t reps, double *avg_us) {
     return CCAL_OK;
 }
 
+int ccal_debug_acc_sum(ccal_ctx *c, const double *rows, int32_t n_rows, int32_t replicas, double out[68]) {
+    if (!c || !rows || !out) return fail(CCAL_E_ARG, "ccal_debug_acc_sum: NULL argument");
+    if (n_rows < 1 || n_rows > 1024 || replicas < 1 || replicas > ACC_MAX_REPLICAS || (replicas & (replicas - 1)) != 0)
+        return fail(CCAL_E_ARG, "ccal_debug_acc_sum: 1..1024 rows, replicas a power of two up to 64");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t b_in = align256(sizeof(double) * (size_t)n_rows * NRED);
+    const int rc = scratch_need(c, b_in + 1024);
+    if (rc) return rc;
+    double *d_in = static_cast<double *>(c->d_scratch), *d_out = reinterpret_cast<double *>(static_cast<char *>(c->d_scratch) + b_in);
+    HIPCHK(hipMemcpyAsync(d_in, rows, sizeof(double) * (size_t)n_rows * NRED, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(launch_acc_debug(c->stream, d_in, n_rows, c->d_acc_scratch, replicas, d_out));
+    HIPCHK(hipMemcpyAsync(out, d_out, sizeof(double) * NRED, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CCAL_OK;
+}
+
 #ifdef CCAL_STAMPS
 int ccal_debug_init_stamps(unsigned long long *out) {
     HIPCHK(hipDeviceSynchronize());

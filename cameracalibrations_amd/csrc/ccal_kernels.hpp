@@ -32,6 +32,8 @@ struct TrialLaunch {              // one launch of k_lm_trial (see ccal_lm.hip)
 };
 hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t);
 int lm_acc_replicas(int nblocks);
+// diagnostics: n_rows rows of 68 doubles added like n_rows workgroups would, read back like a prologue does -> out[68]
+hipError_t launch_acc_debug(hipStream_t stream, const double *vals, int n_rows, long long *acc, int R, double *out);
 // accumulators of trial k - 1 -> out[0..68) (what RCCL / a host hook then sums across GPUs); no-op after `done`
 hipError_t launch_lm_row(hipStream_t stream, const long long *acc, int R, const LmState *st, int k, double *out);
 // multi-GPU, many workgroups per rank: accumulators -> one row -> sum over the node's ranks by direct xGMI

@@ -972,6 +972,34 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_exchange(const long long *__r
 }
 
 // ---------------------------------------------------------------------------------------
+// diagnostics: the exact accumulators on their own (ccal_debug_acc_sum).  "Workgroup" b adds its row of
+// 68 doubles into replica b mod R exactly as a sweep does; one workgroup then reads and decodes the sums
+// exactly as a trial's prologue does.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void k_acc_debug_add(const double *__restrict__ vals, long long *__restrict__ acc, int R) {
+    const int tid = threadIdx.x;
+    if (tid < NRED) acc_add(acc + (size_t)(blockIdx.x & (R - 1)) * ACC_ROW, tid, vals[(size_t)blockIdx.x * NRED + tid]);
+}
+
+__global__ __launch_bounds__(WAVES * 64) void k_acc_debug_read(const long long *__restrict__ acc, int R, double *__restrict__ out) {
+    __shared__ AccPart s_acc[ACC_ROW];
+    const int tid = threadIdx.x;
+    AccRegs q;
+    acc_read_issue(acc, R, tid, q);
+    acc_read_stage(acc, R, s_acc, tid, q);
+    __syncthreads();
+    if (tid < NRED) out[tid] = acc_row_decode(s_acc, tid);
+}
+
+hipError_t launch_acc_debug(hipStream_t stream, const double *vals, int n_rows, long long *acc, int R, double *out) {
+    hipError_t e = hipMemsetAsync(acc, 0, sizeof(long long) * (size_t)R * ACC_ROW, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_acc_debug_add, dim3(n_rows), dim3(128), 0, stream, vals, acc, R);
+    hipLaunchKernelGGL(k_acc_debug_read, dim3(1), dim3(WAVES * 64), 0, stream, acc, R, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------------------
 int lm_sweep_blocks(int N) { return (N + WAVES - 1) / WAVES; }

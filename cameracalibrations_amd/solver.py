@@ -221,6 +221,14 @@ class Solver:
         F.check(F.lib().ccal_debug_image_grams(self._h, F.f64(intr)[1], rp, gp))
         return G
 
+    def debug_acc_sum(self, rows, replicas=8):
+        """Diagnostics: column sums of `rows` (n, 68) through the device's exact accumulators -> sums[68]."""
+        rows, rp = F.f64(np.atleast_2d(rows))
+        assert rows.shape[1] == 68
+        out, o = F.out64(68)
+        F.check(F.lib().ccal_debug_acc_sum(self._h, rp, rows.shape[0], int(replicas), o))
+        return out
+
     def time_sweep(self, reps=50):
         v = C.c_double(0)
         F.check(F.lib().ccal_time_sweep(self._h, int(reps), C.byref(v)))

@@ -245,6 +245,11 @@ int  ccal_detect_corners(ccal_ctx *ctx, const uint8_t *gray, int32_t rows, int32
 /* per-image 16x16 Gram matrices [Je|Ji|e]^T[Je|Ji|e] at the given point -> G [256,N] host */
 int  ccal_debug_image_grams(ccal_ctx *ctx, const double intr[CCAL_NINTR], const double *rt_host,
                             double *G_host);
+/* the exact accumulators on their own: `n_rows` rows of 68 doubles are added as n_rows workgroups of a sweep would
+ * add them (integer atomics into `replicas` replicas), then read and decoded as a trial's prologue does.
+ * out[0..67] = the column sums (the last column carries no value; the error column, 63, turns NaN / +inf when a
+ * NaN / out-of-range value was added). */
+int  ccal_debug_acc_sum(ccal_ctx *ctx, const double *rows, int32_t n_rows, int32_t replicas, double out[68]);
 /* current initial values held by the context: intr[9], rt [6,N] */
 int  ccal_get_init(ccal_ctx *ctx, double intr[CCAL_NINTR], double *rt_host);
 /* average device time (microseconds, HIP events on the context's stream) of `reps` launches

@@ -88,6 +88,47 @@ def test_lm_trajectory_from_oracle_init(name, n, crit):
     assert np.abs(r["tvecs"] - ro["tvecs"]).max() < tol * 100
 
 
+def test_device_accumulators_are_exact():
+    """The exact accumulators on their own (ccal_debug_acc_sum): rows added as workgroups add them (integer atomics,
+    any order), read back and decoded as a trial's prologue does, against exact rational arithmetic: the result is within 4 ulp of the exact sum of the contributions (each truncated at
+    2^-150), whatever their order, magnitudes and cancellation (exact zero when they cancel)."""
+    from fractions import Fraction
+    rng = np.random.default_rng(11)
+
+    def exact(col):
+        t = Fraction(0)
+        for x in col:
+            f = Fraction(float(x))
+            q = f * 2 ** 150                       # truncation towards zero at the accumulators' resolution
+            t += Fraction(int(q) if q >= 0 else -int(-q), 2 ** 150)
+        return t
+
+    with Solver(0) as s:
+        for n_rows, R, lo_exp, hi_exp in ((250, 8, -30, 40), (250, 8, -80, 20), (1024, 8, -140, 57), (37, 2, -60, 0), (512, 64, -100, 50)):
+            rows = rng.standard_normal((n_rows, 68)) * np.exp2(rng.integers(lo_exp, hi_exp, (n_rows, 68)))
+            rows[:, 5] = 1.0 / 3.0                                           # plain sums
+            rows[: n_rows // 2 * 2 : 2, 7] = -rows[1 : n_rows // 2 * 2 : 2, 7]   # cancels to (almost) nothing
+            rows[:, 9] = 0.0
+            rows[:, 67] = 0.0                                                # the pad column carries flags, no value
+            got = s.debug_acc_sum(rows, R)
+            for c in range(67):
+                t = exact(rows[:, c])
+                if t == 0:
+                    assert got[c] == 0.0
+                    continue
+                want = float(t)
+                assert abs(Fraction(got[c]) - t) <= 4 * abs(Fraction(np.spacing(want))), (n_rows, R, c, got[c], want)
+        # flags: a NaN anywhere makes the error column NaN, an out-of-range value makes it +inf
+        rows = rng.standard_normal((9, 68))
+        rows[:, 67] = 0.0
+        rows[3, 12] = np.nan
+        got = s.debug_acc_sum(rows, 8)
+        assert np.isnan(got[63])
+        rows[3, 12] = 1e40
+        got = s.debug_acc_sum(rows, 8)
+        assert np.isposinf(got[63])
+
+
 @pytest.mark.parametrize("name,n", CASES)
 def test_closed_form_initialisation(name, n):
     """Rows A4+A5: focal lengths from homographies and per-view poses, vs the oracle.
