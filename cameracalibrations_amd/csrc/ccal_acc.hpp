@@ -29,25 +29,27 @@ CCAL_ACC_HD int64_t acc_bits(double x) {
 // hi * 2^(52 (j + 1) - 150) exactly, up to bits below 2^-150 which are dropped towards zero).
 // flag: 0 ok, 1 NaN, 2 infinite or |x| >= 2^109 (then lo = hi = 0).
 CCAL_ACC_HD void acc_split(double x, int &j, int64_t &lo, int64_t &hi, int &flag) {
+    // straight-line (selects, no branches): on the device this runs on the critical wave between the workgroup's
+    // last barrier and its atomics, and a nest of divergent early-outs costs more than the arithmetic
     const int64_t bits = acc_bits(x);
     const int ex = (int)((bits >> 52) & 0x7ff);
     const int64_t frac = bits & 0xfffffffffffffll;
-    j = 0; lo = 0; hi = 0; flag = 0;
-    if (ex == 0x7ff) { flag = frac ? 1 : 2; return; }
-    if (ex == 0) return;                                       // zero / subnormal: far below the resolution
-    int64_t m = frac | (1ll << 52);                            // |x| = m * 2^(ex - 1075)
-    int s = ex - 1075 - ACC_LSB_EXP;                           // position of m's lowest bit in the fixed-point number
-    if (s + 53 > ACC_LIMBS * ACC_LIMB_BITS - 1) { flag = 2; return; }
-    if (s < 0) {
-        if (s <= -53) return;
-        m >>= -s;
-        s = 0;
-    }
-    j = s / ACC_LIMB_BITS;
-    const int o = s - ACC_LIMB_BITS * j;
-    lo = (int64_t)(((uint64_t)m << o) & ((1ull << ACC_LIMB_BITS) - 1));
-    hi = m >> (ACC_LIMB_BITS - o);
-    if (bits < 0) { lo = -lo; hi = -hi; }
+    const int s = ex - 1075 - ACC_LSB_EXP;                     // position of the mantissa's lowest bit in the fixed-point number
+    const bool special = ex == 0x7ff;
+    const bool big = !special && (s + 53 > ACC_LIMBS * ACC_LIMB_BITS - 1);
+    flag = special ? (frac ? 1 : 2) : (big ? 2 : 0);
+    // |x| = m * 2^(ex - 1075); zero / subnormal inputs are far below the resolution and count as zero, bits below
+    // 2^-150 are dropped towards zero (a shift of 53 or more leaves nothing of the 53-bit mantissa)
+    const int down = s < 0 ? (-s < 63 ? -s : 63) : 0;
+    const int64_t m = (ex == 0 || flag != 0) ? 0 : ((frac | (1ll << 52)) >> down);
+    const int sp = s < 0 ? 0 : (s > ACC_LIMBS * ACC_LIMB_BITS - 1 ? 0 : s);
+    const int jj = (sp * 1261) >> 16;                          // sp / 52 for 0 <= sp < 260
+    const int o = sp - ACC_LIMB_BITS * jj;
+    j = flag ? 0 : jj;
+    const int64_t l = (int64_t)(((uint64_t)m << o) & ((1ull << ACC_LIMB_BITS) - 1));
+    const int64_t h = m >> (ACC_LIMB_BITS - o);
+    lo = bits < 0 ? -l : l;
+    hi = bits < 0 ? -h : h;
 }
 
 // One limb's total over the replicas (added as int64 by the reader: at most 1024 adds of 52-bit payloads, no
