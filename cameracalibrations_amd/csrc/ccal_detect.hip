@@ -25,7 +25,12 @@
 #include <map>
 #include <vector>
 
+#include <atomic>
+#include <chrono>
+#include <cstring>
+
 #include "ccal_detect.hpp"
+#include "ccal_kernels.hpp"
 #include "ccal_wave.hpp"
 
 namespace ccal {
@@ -45,8 +50,10 @@ __device__ const int RING_DC[16] = {5, 5, 3, 2, 0, -2, -3, -5, -5, -5, -3, -2, 0
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __global__ __launch_bounds__(256) void k_det_load(const uint8_t *__restrict__ src, long long sr, long long sc,
-                                                   double *__restrict__ dst, int rows, int cols) {
+                                                   double *__restrict__ dst, int rows, int cols,
+                                                   unsigned long long *__restrict__ misc) {
     const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) misc[threadIdx.x] = 0ull;   // response maximum, peak count: used by later launches
     if (c < cols) dst[(size_t)r * cols + c] = (double)src[(long long)r * sr + (long long)c * sc];
 }
 
@@ -104,15 +111,43 @@ __global__ __launch_bounds__(256) void k_det_peaks(const double *__restrict__ R,
     const double v = R[(size_t)r * cols + c];
     const double thr = REL_THRESHOLD * __longlong_as_double((long long)*rmax_bits);
     if (!(v > thr) || !(v > 0.0)) return;
-    const int r0 = max(r - NMS_R, 0), r1 = min(r + NMS_R, rows - 1), c0 = max(c - NMS_R, 0), c1 = min(c + NMS_R, cols - 1);
-    for (int rr = r0; rr <= r1; rr++)
-        for (int cc = c0; cc <= c1; cc++) {
-            const double w = R[(size_t)rr * cols + cc];
-            if (w > v) return;
-            if (w == v && (rr < r || (rr == r && cc < c))) return;   // ties: first in raster order wins
-        }
+    // The own row first, then the rows at distance 1, 2, .. 6 in pairs, nearest first: the 13 (26) values of a step are
+    // requested together and most candidates die early (a test after every single load pays a memory round trip per
+    // neighbour: 169 in a row for a true maximum).  Pixels outside the image read as -1 (v > 0: they never suppress).
+    for (int s = 0; s <= NMS_R; s++) {
+        double w[2][2 * NMS_R + 1];
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int j = 0; j <= 2 * NMS_R; j++) {
+                const int rr = h == 0 ? r - s : r + s, cc = c - NMS_R + j;
+                w[h][j] = ((h == 0 || s > 0) && rr >= 0 && rr < rows && cc >= 0 && cc < cols) ? R[(size_t)rr * cols + cc] : -1.0;
+            }
+        bool dead = false;
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int j = 0; j <= 2 * NMS_R; j++) {
+                const int rr = h == 0 ? r - s : r + s, cc = c - NMS_R + j;
+                dead = dead || (w[h][j] > v) || (w[h][j] == v && (rr < r || (rr == r && cc < c)));   // ties: first in raster order wins
+            }
+        if (dead) return;
+    }
     const int k = atomicAdd(count, 1);
     if (k < cap) { list[k].r = r; list[k].c = c; list[k].v = v; }
+}
+
+// peak count and list -> pinned host memory (one workgroup, zero-copy stores)
+__global__ __launch_bounds__(256) void k_det_export(const Peak *__restrict__ list, const int *__restrict__ count, int cap,
+                                                     int *__restrict__ h_count, Peak *__restrict__ h_list,
+                                                     unsigned long long *__restrict__ h_flag, unsigned long long seq) {
+    const int n = min(*count, cap);
+    for (int k = threadIdx.x; k < n; k += 256) h_list[k] = list[k];
+    if (threadIdx.x == 0) *h_count = *count;
+    __threadfence_system();
+    __syncthreads();
+    // the completion word the host spins on, after every thread's stores have been made visible to it
+    if (threadIdx.x == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __device__ __forceinline__ double bilinear(const double *__restrict__ im, int rows, int cols, double rr, double cc) {
@@ -125,26 +160,43 @@ __device__ __forceinline__ double bilinear(const double *__restrict__ im, int ro
            fr * (1 - fc) * im[(size_t)r1 * cols + c0] + fr * fc * im[(size_t)r1 * cols + c1];
 }
 
-// [OCV-K cornerSubPix]: q <- q + G^-1 b with G, b from Gaussian-weighted image gradients
+// [OCV-K cornerSubPix]: q <- q + G^-1 b with G, b from Gaussian-weighted image gradients.  The window weights are
+// computed once per lane, not once per iteration.  (Staging the 32 x 32 pixels around the peak in LDS was measured:
+// slower -- the sixteen loads per sample are independent and hit the cache; the patch's bounds checks cost more.)
 __global__ __launch_bounds__(64) void k_det_subpix(const double *__restrict__ im, int rows, int cols,
-                                                    const Peak *__restrict__ list, int n, double *__restrict__ out) {
+                                                    const Peak *__restrict__ list, int n, double *__restrict__ out,
+                                                    unsigned int *__restrict__ done, unsigned long long *__restrict__ h_flag,
+                                                    unsigned long long seq) {
     const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= n) return;
-    const double pr = list[i].r, pc = list[i].c;
+    const int pri = list[i].r, pci = list[i].c;
+    auto bil = [&](double rr, double cc) -> double { return bilinear(im, rows, cols, rr, cc); };
+    const double pr = pri, pc = pci;
     double qr = pr, qc = pc;
     constexpr int W = 2 * SUBPIX_WIN + 1;
+    constexpr int NPASS = (W * W + 63) / 64;
+    double wgt[NPASS];
+#pragma unroll
+    for (int t = 0; t < NPASS; t++) {
+        const int k = lane + 64 * t;
+        const int wi = k / W - SUBPIX_WIN, wj = k % W - SUBPIX_WIN;       // row, col offsets
+        wgt[t] = exp(-(double)(wi * wi) / (double)(SUBPIX_WIN * SUBPIX_WIN)) * exp(-(double)(wj * wj) / (double)(SUBPIX_WIN * SUBPIX_WIN));
+    }
     for (int it = 0; it < SUBPIX_ITERS; it++) {
         double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
-        for (int k = lane; k < W * W; k += 64) {
-            const int wi = k / W - SUBPIX_WIN, wj = k % W - SUBPIX_WIN;       // row, col offsets
-            const double m = exp(-(double)(wi * wi) / (double)(SUBPIX_WIN * SUBPIX_WIN)) *
-                             exp(-(double)(wj * wj) / (double)(SUBPIX_WIN * SUBPIX_WIN));
-            const double gc = bilinear(im, rows, cols, qr + wi, qc + wj + 1) - bilinear(im, rows, cols, qr + wi, qc + wj - 1);
-            const double gr = bilinear(im, rows, cols, qr + wi + 1, qc + wj) - bilinear(im, rows, cols, qr + wi - 1, qc + wj);
-            const double gcc = gc * gc * m, gcr = gc * gr * m, grr = gr * gr * m;
-            a += gcc; b += gcr; c += grr;
-            bb1 += gcc * wj + gcr * wi;
-            bb2 += gcr * wj + grr * wi;
+#pragma unroll
+        for (int t = 0; t < NPASS; t++) {
+            const int k = lane + 64 * t;
+            if (k < W * W) {
+                const int wi = k / W - SUBPIX_WIN, wj = k % W - SUBPIX_WIN;
+                const double m = wgt[t];
+                const double gc = bil(qr + wi, qc + wj + 1) - bil(qr + wi, qc + wj - 1);
+                const double gr = bil(qr + wi + 1, qc + wj) - bil(qr + wi - 1, qc + wj);
+                const double gcc = gc * gc * m, gcr = gc * gr * m, grr = gr * gr * m;
+                a += gcc; b += gcr; c += grr;
+                bb1 += gcc * wj + gcr * wi;
+                bb2 += gcr * wj + grr * wi;
+            }
         }
         a = wave_sum(a); b = wave_sum(b); c = wave_sum(c); bb1 = wave_sum(bb1); bb2 = wave_sum(bb2);
         const double det = a * c - b * b;
@@ -156,7 +208,12 @@ __global__ __launch_bounds__(64) void k_det_subpix(const double *__restrict__ im
         if (err <= SUBPIX_EPS * SUBPIX_EPS) break;
     }
     if (fabs(qr - pr) > SUBPIX_WIN || fabs(qc - pc) > SUBPIX_WIN) { qr = pr; qc = pc; }
-    if (lane == 0) { out[2 * i] = qr; out[2 * i + 1] = qc; }
+    if (lane == 0) {
+        out[2 * i] = qr; out[2 * i + 1] = qc;
+        // `out` is pinned host memory: the last workgroup to finish raises the completion word the host spins on
+        __threadfence_system();
+        if (atomicAdd(done, 1u) == (unsigned int)(n - 1)) __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 struct P2 { double r, c; };
@@ -299,6 +356,9 @@ void Detector::release() {
     (void)hipFree(d_list); (void)hipFree(d_out); (void)hipFree(d_misc); (void)hipFree(d_taps);
     d_raw = nullptr; d_img = d_tmp = d_g = d_R = d_out = d_taps = nullptr; d_list = nullptr; d_misc = nullptr;
     cap_px = 0;
+    if (h_pin) (void)hipHostFree(h_pin);
+    h_pin = nullptr;
+    pin_img_cap = 0;
 }
 
 #define DCHK(expr)                                                          \
@@ -307,10 +367,27 @@ void Detector::release() {
         if (e_ != hipSuccess) { err = std::string(#expr) + ": " + hipGetErrorString(e_); return -5; } \
     } while (0)
 
+// Spin on the completion word in pinned memory (a blocking stream synchronisation costs tens of microseconds of
+// wake-up latency); after 2 ms the wait becomes a stream synchronisation.
+int Detector::wait_flag(hipStream_t stream, unsigned long long want, std::string &err) {
+    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(h_pin);
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+    bool seen = false;
+    for (long spins = 0; !seen; spins++) {
+        seen = *flag == want;
+        if (!seen && (spins & 255) == 255 && std::chrono::steady_clock::now() > t_end) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) DCHK(hipStreamSynchronize(stream));
+    return 0;
+}
+
 int Detector::detect(hipStream_t stream, const uint8_t *gray, int rows, int cols, long long sr, long long sc, int n1,
                      int n2, double *corners, int *found, double *stage_out, std::string &err) {
     *found = 0;
     const size_t px = (size_t)rows * cols;
+    constexpr size_t PIN_COUNT = 64, PIN_PEAKS = 128, PIN_SUB = PIN_PEAKS + sizeof(Peak) * MAX_PEAKS,
+                     PIN_IMG = PIN_SUB + sizeof(double) * 2 * MAX_PEAKS;
     if (px > cap_px) {
         release();
         DCHK(hipMalloc(&d_raw, px));
@@ -318,45 +395,55 @@ int Detector::detect(hipStream_t stream, const uint8_t *gray, int rows, int cols
         DCHK(hipMalloc(&d_R, px * 8));
         DCHK(hipMalloc(&d_list, sizeof(Peak) * MAX_PEAKS)); DCHK(hipMalloc(&d_out, sizeof(double) * 2 * MAX_PEAKS));
         DCHK(hipMalloc(&d_misc, 64)); DCHK(hipMalloc(&d_taps, sizeof(double) * (2 * BLUR_R + 1)));
+        DCHK(hipHostMalloc(reinterpret_cast<void **>(&h_pin), PIN_IMG + px, hipHostMallocMapped));
+        memset(h_pin, 0, PIN_PEAKS);
+        pin_img_cap = px;
         double taps[2 * BLUR_R + 1], s = 0.0;
         for (int i = -BLUR_R; i <= BLUR_R; i++) s += taps[i + BLUR_R] = std::exp(-0.5 * i * i);
         for (double &t : taps) t /= s;
         DCHK(hipMemcpy(d_taps, taps, sizeof taps, hipMemcpyHostToDevice));
         cap_px = px;
     }
-    // the caller's layout is uploaded as is: bytes span the strided extent
+    unsigned long long *h_flag = reinterpret_cast<unsigned long long *>(h_pin);
+    int *h_count = reinterpret_cast<int *>(h_pin + PIN_COUNT);
+    Peak *h_peaks = reinterpret_cast<Peak *>(h_pin + PIN_PEAKS);
+    double *h_sub = reinterpret_cast<double *>(h_pin + PIN_SUB);
+    // the caller's layout is uploaded as is: bytes span the strided extent (through the pinned block: a plain DMA)
     const long long span = (long long)(rows - 1) * sr + (long long)(cols - 1) * sc + 1;
     if (span > (long long)px || sr < 1 || sc < 1) { err = "image strides must describe a dense rows x cols matrix"; return -1; }
-    DCHK(hipMemcpyAsync(d_raw, gray, (size_t)span, hipMemcpyHostToDevice, stream));
-    DCHK(hipMemsetAsync(d_misc, 0, 64, stream));
+    memcpy(h_pin + PIN_IMG, gray, (size_t)span);
+    DCHK(hipMemcpyAsync(d_raw, h_pin + PIN_IMG, (size_t)span, hipMemcpyHostToDevice, stream));
     const dim3 grid((cols + 255) / 256, rows), block(256);
     unsigned long long *rmax = reinterpret_cast<unsigned long long *>(d_misc);
     int *count = reinterpret_cast<int *>(d_misc) + 4;
-    hipLaunchKernelGGL(k_det_load, grid, block, 0, stream, (const uint8_t *)d_raw, sr, sc, d_img, rows, cols);
+    hipLaunchKernelGGL(k_det_load, grid, block, 0, stream, (const uint8_t *)d_raw, sr, sc, d_img, rows, cols, rmax);
     hipLaunchKernelGGL(k_det_blur, grid, block, 0, stream, (const double *)d_img, d_tmp, rows, cols, 0, (const double *)d_taps);
     hipLaunchKernelGGL(k_det_blur, grid, block, 0, stream, (const double *)d_tmp, d_g, rows, cols, 1, (const double *)d_taps);
     hipLaunchKernelGGL(k_det_chess, grid, block, 0, stream, (const double *)d_g, d_R, rows, cols, rmax);
     hipLaunchKernelGGL(k_det_peaks, grid, block, 0, stream, (const double *)d_R, rows, cols, (const unsigned long long *)rmax,
                        (Peak *)d_list, count, MAX_PEAKS);
+    hipLaunchKernelGGL(k_det_export, dim3(1), dim3(256), 0, stream, (const Peak *)d_list, (const int *)count, MAX_PEAKS, h_count,
+                       h_peaks, h_flag, ++pin_seq);
     DCHK(hipGetLastError());
-    int n = 0;
-    DCHK(hipMemcpyAsync(&n, count, sizeof(int), hipMemcpyDeviceToHost, stream));
-    DCHK(hipStreamSynchronize(stream));
+    int rc = wait_flag(stream, pin_seq, err);
+    if (rc) return rc;
+    int n = *h_count;
     if (stage_out) {          // diagnostics: blurred image and response for stage-wise parity tests
         DCHK(hipMemcpy(stage_out, d_g, px * 8, hipMemcpyDeviceToHost));
         DCHK(hipMemcpy(stage_out + px, d_R, px * 8, hipMemcpyDeviceToHost));
     }
     if (n > MAX_PEAKS) n = MAX_PEAKS;
     if (n < n1 * n2) return 0;
-    std::vector<Peak> peaks(n);
-    DCHK(hipMemcpy(peaks.data(), d_list, sizeof(Peak) * n, hipMemcpyDeviceToHost));
+    std::vector<Peak> peaks(h_peaks, h_peaks + n);
     std::sort(peaks.begin(), peaks.end(), [&](const Peak &x, const Peak &y) { return x.r != y.r ? x.r < y.r : x.c < y.c; });
-    DCHK(hipMemcpyAsync(d_list, peaks.data(), sizeof(Peak) * n, hipMemcpyHostToDevice, stream));   // raster order
-    hipLaunchKernelGGL(k_det_subpix, dim3(n), dim3(64), 0, stream, (const double *)d_img, rows, cols, (const Peak *)d_list, n, d_out);
+    // raster order; the sub-pixel kernel reads the list from, and writes the refined corners to, the pinned block
+    memcpy(h_peaks, peaks.data(), sizeof(Peak) * n);
+    hipLaunchKernelGGL(k_det_subpix, dim3(n), dim3(64), 0, stream, (const double *)d_img, rows, cols, (const Peak *)h_peaks, n, h_sub,
+                       reinterpret_cast<unsigned int *>(d_misc) + 8, h_flag, ++pin_seq);
     DCHK(hipGetLastError());
-    std::vector<double> sub(2 * (size_t)n);
-    DCHK(hipMemcpyAsync(sub.data(), d_out, sizeof(double) * sub.size(), hipMemcpyDeviceToHost, stream));
-    DCHK(hipStreamSynchronize(stream));
+    rc = wait_flag(stream, pin_seq, err);
+    if (rc) return rc;
+    std::vector<double> sub(h_sub, h_sub + 2 * (size_t)n);
     // merge peaks that converged onto the same corner (strongest first), keep raster order
     std::vector<int> order(n), keep;
     for (int k = 0; k < n; k++) order[k] = k;

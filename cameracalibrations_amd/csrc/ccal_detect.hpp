@@ -26,6 +26,13 @@ class Detector {
     double *d_img = nullptr, *d_tmp = nullptr, *d_g = nullptr, *d_R = nullptr, *d_out = nullptr, *d_taps = nullptr;
     void *d_list = nullptr, *d_misc = nullptr;
     size_t cap_px = 0;
+    // pinned, device-mapped host block: completion word | peak count | peak list | refined corners | image staging.
+    // The host waits on the completion word (a one-thread kernel behind the stage raises it) instead of paying the
+    // wake-up latency of a stream synchronisation twice per image, and no copy of a call blocks.
+    unsigned char *h_pin = nullptr;
+    size_t pin_img_cap = 0;
+    unsigned long long pin_seq = 0;
+    int wait_flag(hipStream_t stream, unsigned long long want, std::string &err);
 };
 
 }  // namespace ccal
