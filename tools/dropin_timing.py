@@ -18,11 +18,15 @@ obj = cc.board_template(ex["n_corners"])
 
 
 def t(fn, n):
+    """median over n calls (a mean is at the mercy of the rare tens-of-milliseconds host stall of these boxes)"""
     fn()
-    t0 = time.perf_counter()
+    fn()
+    ts = []
     for _ in range(n):
+        t0 = time.perf_counter()
         r = fn()
-    return 1e3 * (time.perf_counter() - t0) / n, r
+        ts.append(time.perf_counter() - t0)
+    return 1e3 * float(np.median(ts)), r
 
 
 ms, m = t(lambda: cc.fit_model(ex["image_size_wh"], obj, img, ex["n_corners"], True, 1), 50)
