@@ -500,12 +500,17 @@ static LmInit make_init(const ccal_ctx *c) {
     return in;
 }
 
-static int finish_init(ccal_ctx *c, bool intr, bool extr) {
-    // read back what the host mirrors and the failure flags of the initialisation kernels
+// read back what the host mirrors and the failure flags of the initialisation kernels: enqueue ...
+static int finish_init_enqueue(ccal_ctx *c) {
     double *h_intr = reinterpret_cast<double *>(c->h_flags + 4);   // pinned staging (flags: ints 0..3)
     HIPCHK(hipMemcpyAsync(h_intr, c->d_intr0, sizeof(double) * 9, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(c->h_flags, c->d_fail, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    return CCAL_OK;
+}
+
+// ... and, once the copies have landed, check
+static int finish_init_check(ccal_ctx *c, bool intr, bool extr) {
+    const double *h_intr = reinterpret_cast<const double *>(c->h_flags + 4);
     if (via_p2p(c)) {              // a silent peer explains (and outranks) the NaN it left behind
         std::string err;
         if (c->p2p->check_and_clear(err)) return fail(CCAL_E_COMM, "ccal_init_intrinsics: " + err);
@@ -520,6 +525,13 @@ static int finish_init(ccal_ctx *c, bool intr, bool extr) {
         return fail(CCAL_E_DEGENERATE, "ccal_init_extrinsics: pose initialisation failed for " +
                                            std::to_string(c->h_flags[0]) + " image(s)");
     return CCAL_OK;
+}
+
+static int finish_init(ccal_ctx *c, bool intr, bool extr) {
+    int rc = finish_init_enqueue(c);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return finish_init_check(c, intr, extr);
 }
 
 int ccal_init_intrinsics(ccal_ctx *c) {
@@ -805,6 +817,21 @@ int ccal_set_sweep_timing(ccal_ctx *c, int32_t enable) {
     return CCAL_OK;
 }
 
+// rvec,tvec sit at words BLK_EXT.. of each image's block of the accepted parity: N rows of 8 doubles -> dst (host)
+static int enqueue_pose_rows(ccal_ctx *c, double *dst) {
+    HIPCHK(hipMemcpy2DAsync(dst, sizeof(double) * 8, c->d_blk + (size_t)c->h_st->parity * c->N * BLK + BLK_EXT,
+                            sizeof(double) * BLK, sizeof(double) * 8, (size_t)c->N, hipMemcpyDeviceToHost, c->stream));
+    return CCAL_OK;
+}
+
+static void unpack_pose_rows(const ccal_ctx *c, const double *e, double *rvecs, double *tvecs) {
+    for (int i = 0; i < c->N; i++)
+        for (int k = 0; k < 3; k++) {
+            if (rvecs) rvecs[(size_t)3 * i + k] = e[(size_t)i * 8 + k];
+            if (tvecs) tvecs[(size_t)3 * i + k] = e[(size_t)i * 8 + 3 + k];
+        }
+}
+
 int ccal_get_result(ccal_ctx *c, double intr[CCAL_NINTR], double *rvecs, double *tvecs, ccal_stats *stats) {
     if (!c) return fail(CCAL_E_ARG, "ccal_get_result: ctx == NULL");
     if (!c->have_result) return fail(CCAL_E_STATE, "ccal_get_result: no finished fit");
@@ -812,17 +839,11 @@ int ccal_get_result(ccal_ctx *c, double intr[CCAL_NINTR], double *rvecs, double 
     const LmState &r = *c->h_st;
     if (intr) memcpy(intr, r.intr_prev, sizeof(double) * 9);
     if (rvecs || tvecs) {
-        // rvec,tvec sit at words BLK_EXT.. of each image's block of the accepted parity
         std::vector<double> e((size_t)c->N * 8);
-        HIPCHK(hipMemcpy2DAsync(e.data(), sizeof(double) * 8, c->d_blk + (size_t)r.parity * c->N * BLK + BLK_EXT,
-                                sizeof(double) * BLK, sizeof(double) * 8, (size_t)c->N, hipMemcpyDeviceToHost,
-                                c->stream));
+        const int rc = enqueue_pose_rows(c, e.data());
+        if (rc) return rc;
         HIPCHK(hipStreamSynchronize(c->stream));
-        for (int i = 0; i < c->N; i++)
-            for (int k = 0; k < 3; k++) {
-                if (rvecs) rvecs[(size_t)3 * i + k] = e[(size_t)i * 8 + k];
-                if (tvecs) tvecs[(size_t)3 * i + k] = e[(size_t)i * 8 + 3 + k];
-            }
+        unpack_pose_rows(c, e.data(), rvecs, tvecs);
     }
     if (stats) *stats = c->stats;
     return CCAL_OK;
@@ -903,6 +924,9 @@ thread_local ThreadCacheGuard t_cache_guard;
 
 extern "C" {
 
+static int stage_need(ccal_ctx *c, size_t bytes);
+static int signal_and_spin(ccal_ctx *c);
+
 int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int32_t width, int32_t height,
                    double aspect, uint32_t flags, int32_t max_iter, double eps, int32_t device, double K4[4],
                    double dist5[5], double *rvecs, double *tvecs, double *rms, int32_t *iters, ccal_stats *stats) {
@@ -930,11 +954,21 @@ int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int
         if ((rc = ccal_init_extrinsics(c)) < 0) break;
         lm_rc = ccal_lm_run(c);
         const std::string lm_err = g_err;
+        // One read-back for everything the host still needs -- the initialisation's flags and values, the poses --
+        // through pinned memory, and one wait on a completion word instead of two stream synchronisations.
+        const bool poses = lm_rc >= 0 && c->have_result && (rvecs || tvecs);
+        if ((rc = finish_init_enqueue(c)) < 0) break;
+        if (poses) {
+            if ((rc = stage_need(c, sizeof(double) * 8 * (size_t)c->N)) < 0) break;
+            if ((rc = enqueue_pose_rows(c, static_cast<double *>(c->h_stage))) < 0) break;
+        }
+        if ((rc = signal_and_spin(c)) < 0) break;
         // initialisation failures explain (and outrank) whatever the LM reported on garbage
-        if ((rc = finish_init(c, !guess, true)) < 0) break;
+        if ((rc = finish_init_check(c, !guess, true)) < 0) break;
         if ((rc = lm_rc) < 0) { g_err = lm_err; break; }
         ccal_stats st;
-        if ((rc = ccal_get_result(c, intr, rvecs, tvecs, &st)) < 0) break;
+        if ((rc = ccal_get_result(c, intr, nullptr, nullptr, &st)) < 0) break;
+        if (poses) unpack_pose_rows(c, static_cast<const double *>(c->h_stage), rvecs, tvecs);
         if (K4) memcpy(K4, intr, sizeof(double) * 4);
         if (dist5) memcpy(dist5, intr + 4, sizeof(double) * 5);
         if (rms) *rms = st.rms;
@@ -1102,6 +1136,24 @@ static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 // grow-only pinned host staging for mid-size transfers (caller buffers are pageable: copied through here, the
 // DMA itself always runs pinned <-> device); beyond STAGE_MAX the runtime's own pageable path is used
 static constexpr size_t STAGE_MAX = 16u << 20;
+// Wait for everything enqueued on the context's stream so far: a one-thread kernel behind it raises a sequence number
+// in pinned memory and the host spins on that word (a blocking stream synchronisation costs tens to hundreds of
+// microseconds of wake-up latency per call); after 2 ms of spinning the wait becomes a stream synchronisation.
+static int signal_and_spin(ccal_ctx *c) {
+    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(static_cast<char *>(c->h_pin) + PIN_BYTES);
+    const unsigned long long want = ++c->pin_seq;
+    HIPCHK(launch_signal(c->stream, const_cast<unsigned long long *>(flag), want));
+    const double t_end = now_s() + 2e-3;
+    bool seen = false;
+    for (long spins = 0; !seen; spins++) {
+        seen = *flag == want;
+        if (!seen && (spins & 255) == 255 && now_s() > t_end) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) HIPCHK(hipStreamSynchronize(c->stream));
+    return CCAL_OK;
+}
+
 static int stage_need(ccal_ctx *c, size_t bytes) {
     if (bytes <= c->stage_cap) return CCAL_OK;
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1167,19 +1219,9 @@ static int map_many(ccal_ctx *c, const double *in, int32_t M, int32_t N, bool pe
         if (staged) memcpy(out, hs + b_rt + b_in, 8 * n_out);
         return CCAL_OK;
     }
-    // zero-copy path: a one-thread kernel behind the map kernel raises a sequence number in pinned memory; spin on it
-    // (a blocking stream synchronisation costs tens to hundreds of microseconds of wake-up latency per call)
-    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(static_cast<char *>(c->h_pin) + PIN_BYTES);
-    const unsigned long long want = ++c->pin_seq;
-    HIPCHK(launch_signal(c->stream, const_cast<unsigned long long *>(flag), want));
-    const double t_end = now_s() + 2e-3;
-    bool seen = false;
-    for (long spins = 0; !seen; spins++) {
-        seen = *flag == want;
-        if (!seen && (spins & 255) == 255 && now_s() > t_end) break;
-    }
-    std::atomic_thread_fence(std::memory_order_acquire);
-    if (!seen) HIPCHK(hipStreamSynchronize(c->stream));
+    // zero-copy path: wait for the map kernel without a stream synchronisation
+    const int rc = signal_and_spin(c);
+    if (rc) return rc;
     memcpy(out, d_out, 8 * n_out);
     return CCAL_OK;
 }
