@@ -279,7 +279,10 @@ def fit_model(sz, objpoints, imgpointss, n_corners, with_distortion, aspect, dev
     """
     P = int(n_corners[0]) * int(n_corners[1])
     obj = np.asarray(objpoints, dtype=np.float32).reshape(P, 3)
-    img = np.stack([np.asarray(m, dtype=np.float32).reshape(P, 2) for m in imgpointss])
+    if isinstance(imgpointss, np.ndarray):           # already one array of all images' corners
+        img = np.ascontiguousarray(imgpointss, dtype=np.float32).reshape(-1, P, 2)
+    else:
+        img = np.stack([np.asarray(m, dtype=np.float32).reshape(P, 2) for m in imgpointss])
     K4 = np.zeros(4)
     dist5 = np.zeros(5)
     N = img.shape[0]
@@ -292,6 +295,6 @@ def fit_model(sz, objpoints, imgpointss, n_corners, with_distortion, aspect, dev
                                    reference_flags(with_distortion), CRITERIA[0], CRITERIA[1], int(device),
                                    K4.ctypes.data_as(dp), dist5.ctypes.data_as(dp), rv.ctypes.data_as(dp),
                                    tv.ctypes.data_as(dp), C.byref(rms), C.byref(iters), C.byref(st)))
-    return SimpleNamespace(k=float(dist5[0]), Rs=[r.copy() for r in rv], ts=[t.copy() for t in tv],
+    return SimpleNamespace(k=float(dist5[0]), Rs=list(rv), ts=list(tv),      # per-image vectors (rows of the two result arrays)
                            frow=float(K4[0]), fcol=float(K4[1]), crow=float(K4[2]), ccol=float(K4[3]),
                            rms=rms.value, iters=iters.value, stats=st.asdict())
