@@ -741,7 +741,7 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
     ISTAMP(3);
     ICOUNT(4, n_j); ICOUNT(5, n_e); ICOUNT(6, iters);
 #ifdef CCAL_STAMPS
-    IBLK(0, memtime_now() - t_begin); IBLK(2, iters); IBLK(3, n_j);
+    IBLK(0, memtime_now() - t_begin); IBLK(2, iters); IBLK(3, n_e);
 #endif
     bool finite = true;
 #pragma unroll

@@ -79,5 +79,8 @@ with Solver(0) as s:
     L.ccal_debug_init_blocks(bb)
     b = np.array(bb[:], dtype=np.int64).reshape(4096, 4)[:1000]
     print("per-image k_init_extrinsics cycles: min %d median %d p90 %d max %d" % (b[:, 0].min(), np.median(b[:, 0]), np.percentile(b[:, 0], 90), b[:, 0].max()))
-    for j, n in ((1, "homography polish iters"), (2, "pose LM iters"), (3, "pose Jacobian passes")):
+    for j, n in ((1, "homography polish iters"), (2, "pose LM iters"), (3, "pose error passes")):
         print("  ", n, np.bincount(b[:, j]).tolist())
+    slow = np.argsort(b[:, 0])[-8:]
+    print("   slowest images: (cycles, pose iters, error passes)", [(int(b[i, 0]), int(b[i, 2]), int(b[i, 3])) for i in slow])
+    print("   rejected pose steps (error passes - iterations): total", int((b[:, 3] - b[:, 2]).sum()), "max per image", int((b[:, 3] - b[:, 2]).max()))
