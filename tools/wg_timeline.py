@@ -60,6 +60,10 @@ for n in a.images:
          "sweep_ns_shared_p50": int(np.median((end - pro)[dbl])) if dbl.any() else None,
          "life_ns_shared_max": int((end - start)[dbl].max()) if dbl.any() else None,
          "workgroup0": {"start": int(start[0]), "prologue_done": int(pro[0]), "exit": int(end[0])}}
+    oe = np.argsort(end)
+    r["last_exits"] = [(int(i), int(end[i])) for i in oe[-6:]]          # (workgroup, exit time): who finishes last
+    r["exit_ns"] = {"p50": int(np.median(end)), "p90": int(np.percentile(end, 90)), "p99": int(np.percentile(end, 99))}
+    r["prologue_done_ns"] = {"p50": int(np.median(pro)), "max_other_than_0": int(pro[1:].max()) if len(pro) > 1 else None}
     by_xcc = {int(x): int((xcc == x).sum()) for x in np.unique(xcc)}
     r["workgroups_per_xcd"] = by_xcc
     o = np.argsort(start)
