@@ -123,13 +123,23 @@ __global__ __launch_bounds__(256) void k_errors(const double *__restrict__ obj, 
 }
 
 // fixed-order sum of the per-image partials [4,N] -> out[4]
-__global__ __launch_bounds__(64) void k_errors_reduce(const double *__restrict__ partials, double *__restrict__ out,
-                                                      int N) {
-    const int j = threadIdx.x;
-    if (j >= 4) return;
+// (image order, one running sum per metric: the same bits for any N; the partials come through LDS in coalesced chunks
+//  so that the four sequential sums are add-bound, not one memory round trip per image)
+__global__ __launch_bounds__(256) void k_errors_reduce(const double *__restrict__ partials, double *__restrict__ out,
+                                                       int N) {
+    constexpr int CHUNK = 2048;                       // images per staging round (64 KB)
+    __shared__ double buf[4 * CHUNK];
+    const int tid = threadIdx.x;
     double s = 0.0;
-    for (int i = 0; i < N; i++) s += partials[(size_t)4 * i + j];
-    out[j] = s;
+    for (int i0 = 0; i0 < N; i0 += CHUNK) {
+        const int n = min(CHUNK, N - i0);
+        for (int k = tid; k < 4 * n; k += 256) buf[k] = partials[(size_t)4 * i0 + k];
+        __syncthreads();
+        if (tid < 4)
+            for (int i = 0; i < n; i++) s += buf[4 * i + tid];
+        __syncthreads();
+    }
+    if (tid < 4) out[tid] = s;
 }
 
 // Rectified view of one image (reference src/plot_calibration.jl:15-22,40: `warp(img, tform, axs)` with
@@ -198,7 +208,7 @@ hipError_t launch_errors(hipStream_t stream, const double *obj, const double *im
                          const double *rt, const double *inv_pts, double *partials, int N, int n1, int n2, int S) {
     const size_t lds = sizeof(double) * 3 * (size_t)n1 * n2;
     hipLaunchKernelGGL(k_errors, dim3(N), dim3(256), lds, stream, obj, img, in, rt, inv_pts, partials, n1, n2, S);
-    hipLaunchKernelGGL(k_errors_reduce, dim3(1), dim3(64), 0, stream, partials, partials + (size_t)4 * N, N);
+    hipLaunchKernelGGL(k_errors_reduce, dim3(1), dim3(256), 0, stream, partials, partials + (size_t)4 * N, N);
     return hipGetLastError();
 }
 
