@@ -94,11 +94,17 @@ __global__ __launch_bounds__(256) void k_det_chess(const double *__restrict__ g,
         }
         R[(size_t)r * cols + c] = v;
     }
-    // block maximum -> one atomic per wave (positive doubles order like their bit patterns)
+    // block maximum -> one atomic per workgroup (positive doubles order like their bit patterns)
+    __shared__ double s_max[4];
     double m = v > 0.0 ? v : 0.0;
 #pragma unroll
     for (int k = 32; k > 0; k >>= 1) m = fmax(m, __shfl_xor(m, k, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(rmax_bits, (unsigned long long)__double_as_longlong(m));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
+        if (m > 0.0) atomicMax(rmax_bits, (unsigned long long)__double_as_longlong(m));
+    }
 }
 
 struct Peak { int r, c; double v; };
