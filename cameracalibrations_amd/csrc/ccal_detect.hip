@@ -112,35 +112,48 @@ struct Peak { int r, c; double v; };
 __global__ __launch_bounds__(256) void k_det_peaks(const double *__restrict__ R, int rows, int cols,
                                                     const unsigned long long *__restrict__ rmax_bits,
                                                     Peak *__restrict__ list, int *__restrict__ count, int cap) {
+    // A few hundred pixels of an image pass the threshold, and the response was just written: every dependent read is
+    // a round trip to memory.  So the WAVE tests its candidates, up to four at a time: the 169 neighbours of a
+    // candidate are three loads spread over the 64 lanes, all candidates' loads are in flight together, and a ballot
+    // says whether any neighbour suppresses it (greater, or equal and earlier in raster order).  Pixels outside the
+    // image read as -1 (a candidate is positive).
+    const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-    if (c >= cols) return;
-    const double v = R[(size_t)r * cols + c];
+    const double v = c < cols ? R[(size_t)r * cols + c] : 0.0;
     const double thr = REL_THRESHOLD * __longlong_as_double((long long)*rmax_bits);
-    if (!(v > thr) || !(v > 0.0)) return;
-    // The own row first, then the rows at distance 1, 2, .. 6 in pairs, nearest first: the 13 (26) values of a step are
-    // requested together and most candidates die early (a test after every single load pays a memory round trip per
-    // neighbour: 169 in a row for a true maximum).  Pixels outside the image read as -1 (v > 0: they never suppress).
-    for (int s = 0; s <= NMS_R; s++) {
-        double w[2][2 * NMS_R + 1];
+    unsigned long long todo = __ballot(c < cols && v > thr && v > 0.0);
+    constexpr int W = 2 * NMS_R + 1, NW = W * W;        // 13, 169
+    while (todo != 0ull) {
+        int src[4];
+        double w[4][3];
 #pragma unroll
-        for (int h = 0; h < 2; h++)
+        for (int q = 0; q < 4; q++) {
+            src[q] = todo != 0ull ? (int)__builtin_ctzll(todo) : -1;
+            if (src[q] >= 0) todo &= todo - 1ull;
+            const int cq = c - lane + (src[q] >= 0 ? src[q] : 0);
 #pragma unroll
-            for (int j = 0; j <= 2 * NMS_R; j++) {
-                const int rr = h == 0 ? r - s : r + s, cc = c - NMS_R + j;
-                w[h][j] = ((h == 0 || s > 0) && rr >= 0 && rr < rows && cc >= 0 && cc < cols) ? R[(size_t)rr * cols + cc] : -1.0;
+            for (int t = 0; t < 3; t++) {
+                const int e = lane + 64 * t, rr = r + e / W - NMS_R, cc = cq + e % W - NMS_R;
+                w[q][t] = (src[q] >= 0 && e < NW && rr >= 0 && rr < rows && cc >= 0 && cc < cols) ? R[(size_t)rr * cols + cc] : -1.0;
             }
-        bool dead = false;
+        }
 #pragma unroll
-        for (int h = 0; h < 2; h++)
+        for (int q = 0; q < 4; q++) {
+            if (src[q] < 0) continue;                           // wave-uniform
+            const int cq = c - lane + src[q];
+            const double vq = __shfl(v, src[q], 64);
+            bool dead = false;
 #pragma unroll
-            for (int j = 0; j <= 2 * NMS_R; j++) {
-                const int rr = h == 0 ? r - s : r + s, cc = c - NMS_R + j;
-                dead = dead || (w[h][j] > v) || (w[h][j] == v && (rr < r || (rr == r && cc < c)));   // ties: first in raster order wins
+            for (int t = 0; t < 3; t++) {
+                const int e = lane + 64 * t, rr = r + e / W - NMS_R, cc = cq + e % W - NMS_R;
+                dead = dead || (w[q][t] > vq) || (w[q][t] == vq && (rr < r || (rr == r && cc < cq)));   // ties: first in raster order wins
             }
-        if (dead) return;
+            if (__ballot(dead) == 0ull && lane == src[q]) {
+                const int k = atomicAdd(count, 1);
+                if (k < cap) { list[k].r = r; list[k].c = c; list[k].v = v; }
+            }
+        }
     }
-    const int k = atomicAdd(count, 1);
-    if (k < cap) { list[k].r = r; list[k].c = c; list[k].v = v; }
 }
 
 // peak count and list -> pinned host memory (one workgroup, zero-copy stores)
