@@ -247,6 +247,27 @@ def test_maps_and_errors_match_oracle():
             assert abs(eg[key] - eo[key]) < 1e-10 * max(1.0, eo[key]), key
 
 
+def test_error_metrics_over_many_images_match_oracle():
+    """`ccal_errors` sums its per-image partials in image order through LDS in chunks of 2048 images: 4500 images
+    (three chunks, the last one partial) of a small board against the oracle -- the sums do not depend on N's
+    relation to the chunk."""
+    rng = np.random.default_rng(9)
+    N, nc = 4500, (4, 3)
+    P = nc[0] * nc[1]
+    f, c, k, cs = np.array([820.0, 815.0]), np.array([301.5, 399.0]), -0.07, 2.0
+    obj = np.stack([np.arange(P) % nc[0], np.arange(P) // nc[0], np.zeros(P)], axis=1).astype(np.float64) * cs
+    rv = rng.uniform(-0.4, 0.4, (N, 3))
+    tv = np.c_[rng.uniform(-2, 0, (N, 2)), rng.uniform(7, 12, N)]
+    with Solver(0) as s:
+        img = s.project_many(obj, f, c, k, rv, tv, cs) + rng.normal(0, 0.3, (N, P, 2))
+        pts = rng.random((N, 10, 2)) * 500 + 50
+        args = (nc, obj, img, f, c, k, rv, tv, cs)
+        eg, eo = s.errors(*args, inv_pts=pts), orc.errors(*args, inv_pts=pts)
+    for key in eo:
+        assert abs(eg[key] - eo[key]) < 1e-10 * max(1.0, eo[key]), key
+    assert 0.35 < eo["reprojection"] < 0.5            # the injected 0.3 px per coordinate
+
+
 @pytest.mark.parametrize("name", ["C3", "C5"])
 def test_full_size_properties(name):
     """BASELINE.json full sizes (C3: 1000 x 54; C5: 10000 x 150 on one GPU), checked through
