@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- corner-residuals/sec of the device-side calibrateCamera LM loop (BASELINE.json).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Headline workload (config.workload)
@@ -241,6 +241,66 @@ def detect_block(with_cpu=True, reps=10):
     return out
 
 
+class BlockFailed(RuntimeError):
+    """Raised by EVERY rank at the same point of a block (after an all_agree), so that a per-block try / except never
+    lets one rank skip a collective the others enter."""
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as plain child processes of THIS process --
+    which has made no HIP call and never will -- with the environment torch.distributed.run would give them, relay
+    their output (rank 0 prints the JSON line), and exit non-zero if any of them does."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CCAL_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the inbox handles cross processes
+        env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc, deadline = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0) and deadline is None:
+                # a rank died: give the others a while to notice (bounded waits in the library), then end them
+                rc, deadline = p.returncode, time.time() + float(os.environ.get("CCAL_BENCH_GRACE_S", "30"))
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()                                      # (this exact child, by its handle)
+        time.sleep(0.05)
+    for p in procs:
+        rc = rc or (p.returncode or 0)
+    return rc
+
+
+def dry_run(args):
+    """The launch plumbing without a GPU: every rank joins a gloo group over the environment it was started with,
+    the ranks all-reduce their numbers and rank 0 prints one JSON line."""
+    import torch
+    import torch.distributed as dist
+    world, rank = args.gpus, int(os.environ.get("RANK", "0"))
+    if int(os.environ.get("WORLD_SIZE", "1")) != world:
+        raise SystemExit(f"bench.py: --gpus {world} but WORLD_SIZE={os.environ.get('WORLD_SIZE')} in the environment")
+    if os.environ.get("CCAL_BENCH_FAIL_RANK") == str(rank):        # (tests: a rank that dies before the rendezvous)
+        return 7
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.all_reduce(t)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "sum_of_rank_numbers": int(t.item()),
+                          "launcher": "own child processes" if os.environ.get("CCAL_BENCH_CHILD") else "external"}))
+    return 0
+
+
 class Job:
     """One rank's side of the bench: process group, transports, timing helpers."""
 
@@ -252,7 +312,8 @@ class Job:
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         if self.world > 1:
-            assert int(os.environ.get("WORLD_SIZE", "1")) == self.world, "launch with torch.distributed.run --nproc-per-node N"
+            if int(os.environ.get("WORLD_SIZE", "1")) != self.world:
+                raise SystemExit(f"bench.py: --gpus {self.world} but WORLD_SIZE={os.environ.get('WORLD_SIZE')} in the environment")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if args.share_gpu:
                 self.local_rank = 0
@@ -264,6 +325,7 @@ class Job:
                                         device_id=torch.device("cuda", self.local_rank))
         else:
             torch.cuda.set_device(0)
+        self.shared_device = False
         self.dev = torch.device("cuda", self.local_rank)
         self.cdev = "cpu" if (self.world > 1 and args.share_gpu) else self.dev   # where torch.distributed tensors live
 
@@ -279,6 +341,19 @@ class Job:
         if self.world > 1:
             self.dist.barrier()
         self.torch.cuda.synchronize()
+
+    def together(self, fn, what):
+        """Run the rank-local `fn`; all ranks then agree on the outcome and either all go on or all raise BlockFailed
+        here.  (fn may make library calls that exchange rows with the peers: those waits are bounded, a peer's failure
+        comes back as an error on every rank.)"""
+        ok, why, val = True, "", None
+        try:
+            val = fn()
+        except Exception as exc:      # noqa: BLE001
+            ok, why = False, f"{what}: {exc}"
+        if not self.all_agree(ok):
+            raise BlockFailed(why or f"{what}: a peer rank failed")
+        return val
 
     def max_over_ranks(self, x):
         if self.world == 1:
@@ -301,7 +376,10 @@ class Job:
         if want == "p2p":
             why = ""
             try:
-                sol.init_p2p(world, rank, n_total, allgather_bytes_via_torch())   # (the all-gather inside is always joined)
+                # (the all-gather inside is always joined; ranks that find a device id twice -- a rehearsal on one GPU --
+                # all take the one-workgroup exchange, so that a waiting rank holds one compute unit, not a grid)
+                self.shared_device = sol.init_p2p(world, rank, n_total, allgather_bytes_via_torch(),
+                                                  shared_device=True if self.args.share_gpu else None)
                 ok = True
             except Exception as exc:      # noqa: BLE001
                 ok, why = False, str(exc)
@@ -317,7 +395,8 @@ class Job:
                 except Exception as exc:  # noqa: BLE001
                     ok, why = False, str(exc)
                 if self.all_agree(ok):
-                    return "p2p (direct xGMI row exchange kernels, self-tested)"
+                    return ("p2p (direct xGMI row exchange kernels, self-tested" +
+                            ("; one exchange workgroup per rank: the ranks share a GPU)" if self.shared_device else ")"))
             print(f"[bench] rank {rank}: direct exchange unavailable ({why or 'a peer failed'}); all ranks use RCCL",
                   file=sys.stderr)
         if want in ("p2p", "rccl") and not self.args.share_gpu:   # (RCCL refuses two ranks on one device: rehearsals skip it)
@@ -351,49 +430,113 @@ class Job:
     # ---- one workload: solver set-up, timed solves, launch timing ----
     def make_solver(self, wl, my_img, n_total, criteria):
         from cameracalibrations_amd.solver import Solver
-        img_dev = self.torch.from_numpy(np.ascontiguousarray(my_img)).to(self.dev)   # inputs resident in HBM
-        self.torch.cuda.synchronize()
-        # the context's own non-blocking stream (not torch's legacy default stream, which serialises with every
-        # blocking stream of the process): the timed region is bracketed by device-wide synchronisation anyway
-        s = Solver(self.local_rank)
-        s.set_problem(wl.obj, my_img.shape[0], wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=criteria[0],
-                      eps=criteria[1])
-        s.set_image_points(img_dev)
-        comm = self.attach_comm(s, n_total)
-        s.init_intrinsics()
-        s.init_extrinsics()
+
+        def local():
+            img_dev = self.torch.from_numpy(np.ascontiguousarray(my_img)).to(self.dev)   # inputs resident in HBM
+            self.torch.cuda.synchronize()
+            # the context's own non-blocking stream (not torch's legacy default stream, which serialises with every
+            # blocking stream of the process): the timed region is bracketed by device-wide synchronisation anyway
+            s = Solver(self.local_rank)
+            s.set_problem(wl.obj, my_img.shape[0], wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=criteria[0],
+                          eps=criteria[1])
+            s.set_image_points(img_dev)
+            return s, img_dev
+        s, img_dev = self.together(local, "solver set-up")
+        comm = self.attach_comm(s, n_total)                    # (decides every stage with all ranks itself)
+
+        def init():
+            s.init_intrinsics()
+            s.init_extrinsics()
+        self.together(init, "closed-form initialisation")
         return s, img_dev, comm
 
     def timed_solves(self, s, steps, warmup):
-        for _ in range(warmup):
-            s.lm_run()
+        self.together(lambda: [s.lm_run() for _ in range(warmup)], "warm-up solves")
         self.barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            s.lm_run()
-        self.barrier()
-        return self.max_over_ranks(time.perf_counter() - t0), s.result()
+        ok, why = True, ""
+        try:
+            for _ in range(steps):
+                s.lm_run()
+        except Exception as exc:      # noqa: BLE001
+            ok, why = False, str(exc)
+        self.barrier()                                         # (reached by every rank whatever happened above)
+        dt = time.perf_counter() - t0
+        if not self.all_agree(ok):
+            raise BlockFailed(why or "timed solves: a peer rank failed")
+        return self.max_over_ranks(dt), s.result()
 
     def launch_timing(self, s, steps):
         """mean device time of the sweeping k_lm_trial launches inside solves (HIP events bound to the dispatches on
         the launch stream) and of back-to-back first-trial launches"""
-        s.set_sweep_timing(True)
-        us, n_timed, t1 = 0.0, 0, time.perf_counter()
-        for _ in range(steps):
-            s.lm_run()
-            rr = s.result()
-            us += rr["sweep_us"] * rr["timed_sweeps"]
-            n_timed += rr["timed_sweeps"]
-        self.torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        s.set_sweep_timing(False)
-        return us / max(n_timed, 1), n_timed, s.time_sweep(200), dt / max(steps, 1)
+        def timed():
+            s.set_sweep_timing(True)
+            us, n_timed, t1, self.solve_kernels_us = 0.0, 0, time.perf_counter(), 0.0
+            for _ in range(steps):
+                s.lm_run()
+                rr = s.result()
+                us += rr["sweep_us"] * rr["timed_sweeps"]
+                n_timed += rr["timed_sweeps"]
+                self.solve_kernels_us += rr["solve_kernels_us"] / max(steps, 1)   # all launches of a solve, summed
+            self.torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            s.set_sweep_timing(False)
+            return us / max(n_timed, 1), n_timed, s.time_sweep(200), dt / max(steps, 1)
+        return self.together(timed, "launch timing")
+
+    def eager_solves(self, s, steps, warmup):
+        """the same solves launched kernel by kernel instead of replayed as one hipGraph (host cost only differs)"""
+        s.set_graph(False)
+        try:
+            return self.timed_solves(s, steps, warmup)[0]
+        finally:
+            s.set_graph(True)
 
 
 def shard(wl, world, rank):
     from cameracalibrations_amd.distributed import shard_range
     lo, hi = shard_range(wl.n_images, world, rank)
     return wl.img[lo:hi]
+
+
+# Latency floor of ONE LM trial, from quantities the kernel does not choose (measured constants: the guide's price list
+# and profiles/r02_latency_probe.txt, tools/lat_probe.hip): what any one-launch-per-trial design pays when every image
+# has a SIMD to itself (the C3 regime).  Not this kernel's own instruction stream: the kernel sits well above it.
+CLOCK_GHZ = 2.3                 # measured in-kernel clock of these launches (profiles/r02_wave_stamps.json)
+LAT = {"fma": 4.2, "rcp": 16.2, "rsq": 16.2, "dpp": 12.2, "readlane": 28.2, "lds_round_trip": 128.0,   # cycles
+       "global_state": 740.0, "global_atomics": 480.0}      # dependent global round trips at kernel start / end (DESIGN 4)
+LATENCY_FLOOR_SOURCE = (
+    "boundary: dependent kernel boundary, guide price list; global: the two true dependent global round trips of a trial "
+    "(previous state + accumulators in, 740 cycles; the memory-side atomics out, 480 cycles; DESIGN.md section 4); chain: the "
+    "minimum dependent FP64 chain of one image's trial at the measured per-step latencies of profiles/r02_latency_probe.txt "
+    "(v_fma_f64 4.2, v_rcp/v_rsq_f64 16.2, v_mov_b64_dpp 12.2, readlane + use 28.2 cycles; LDS write -> read 128) -- limbs -> "
+    "doubles 10 fma; 9 Gauss-Jordan pivots x (dpp + rcp + 3 fma) + quotient; state hand-off 2 LDS round trips; pose 1 mul + "
+    "4 dpp adds + readlane + 1 add; rotation series 3 + 11 + 4 fma; projection + Jacobian row 3 + 1 + rcp + 4 + 18 fma; "
+    "rows -> tile -> operands 1 LDS round trip; Gram -> LDS -> factor 1 round trip; 6 Cholesky columns x (fma + rsq + 6 "
+    "refinement steps + mul); 6 forward-substitution steps x 2; Y -> LDS, 6 fma dots, workgroup sum through LDS, 3 adds, "
+    "limb split ~ 15 integer steps; gram: the image's 2P x 16 Gram (symmetric half, 2 x 136 flop per row) at the FP64 matrix "
+    "rate of ONE SIMD, 32 flop per cycle -- a throughput term, one image per SIMD")
+
+
+def latency_floor(P):
+    """-> (floor in us, its terms in us): boundary + dependent global round trips + dependent FP64 chain + Gram"""
+    L = LAT
+    chain = (10 * L["fma"]                                                  # limbs -> doubles
+             + 9 * (L["dpp"] + L["rcp"] + 3 * L["fma"]) + L["rcp"] + 6 * L["fma"] + L["dpp"]   # damped 9x9 solve, candidate
+             + 2 * L["lds_round_trip"]                                      # state: wave 0 -> LDS -> every wave
+             + L["fma"] + 4 * (L["dpp"] + L["fma"]) + L["readlane"] + L["fma"]                 # candidate pose
+             + 18 * L["fma"]                                                # R, K: |r|^2, 11-term Horner, entries
+             + 4 * L["fma"] + L["rcp"] + 4 * L["fma"] + 18 * L["fma"]       # X, 1/Z (+2 Newton), x .. residual / Jacobian row
+             + 2 * L["lds_round_trip"]                                      # rows -> tile -> operands; Gram -> LDS -> factor
+             + 6 * (L["fma"] + L["rsq"] + 7 * L["fma"])                     # Cholesky: pivot, rsqrt + refinement, scale
+             + 12 * L["fma"]                                                # forward substitution
+             + 2 * L["lds_round_trip"] + 6 * L["fma"] + 3 * L["fma"] + 15 * L["fma"])          # Y, dots, workgroup sum, limb split
+    gram = 2.0 * P * 136 * 2 / 32.0                                         # cycles on one SIMD's matrix pipe
+    terms = {"boundary": KERNEL_BOUNDARY_US,
+             "global_round_trips": (L["global_state"] + L["global_atomics"]) / (CLOCK_GHZ * 1e3),
+             "dependent_fp64_chain": chain / (CLOCK_GHZ * 1e3),
+             "gram_at_matrix_peak_one_simd": gram / (CLOCK_GHZ * 1e3)}
+    return sum(terms.values()), terms
 
 
 def roofline_block(N_rank, P, K, sweep_us, n_timed, b2b_us, events_ms_per_step, kernel):
@@ -418,18 +561,14 @@ def roofline_block(N_rank, P, K, sweep_us, n_timed, b2b_us, events_ms_per_step, 
     if pmc and (N_rank, P) == (1000, 54) and "ccal::k_lm_trial" in pmc:
         out["traffic"] = float(pmc["ccal::k_lm_trial"]["hbm_bytes_per_launch"])
         out["traffic_source"] = "committed profile profiles/r02_pmc_traffic_summary.json (not measured in this run)"
-    # latency floor: with one wavefront per SIMD a launch cannot be shorter than a kernel boundary plus
-    # one wavefront's own dependent instruction stream; the stream length comes from the committed s_memtime stamps
-    st = committed_profile("r02_wave_stamps.json")
-    if st and (N_rank, P) == (st.get("N"), st.get("P")):
-        wave_us = st["wave_cycles"] / st["clock_mhz"]
-        out["latency_floor_us"] = KERNEL_BOUNDARY_US + wave_us
-        out["frac_of_floor"] = (KERNEL_BOUNDARY_US + wave_us) / sweep_us if sweep_us > 0 else None
-        out["latency_floor_source"] = (f"{KERNEL_BOUNDARY_US} us kernel boundary (guide) + one wavefront's instruction stream, "
-                                       f"{st['wave_cycles']} shader cycles at {st['clock_mhz']:.0f} MHz "
-                                       "(profiles/r02_wave_stamps.json, diagnostic build)")
-    else:
-        out["latency_floor_us"] = out["frac_of_floor"] = None
+    floor_us, terms = latency_floor(P)
+    if N_rank > 1024:      # more images than SIMDs: a launch is FP64 throughput, not one image's latency chain
+        terms = {"boundary": KERNEL_BOUNDARY_US, "fp64_flop_at_vector_peak": flops / (FP64_PEAK_TFLOPS * 1e6)}
+        floor_us = sum(terms.values())
+    out["latency_floor_us"] = floor_us
+    out["frac_of_floor"] = floor_us / sweep_us if sweep_us > 0 else None
+    out["latency_floor_terms_us"] = terms
+    out["latency_floor_source"] = LATENCY_FLOOR_SOURCE
     return out
 
 
@@ -478,9 +617,18 @@ def main():
     ap.add_argument("--timed-only", action="store_true",
                     help="profiling runs: only the timed solves of the headline (no converged-criteria run, no extras), so "
                          "that counter means are means over the timed region's launches")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous of the ranks only (gloo, no GPU work): checks the launch plumbing, e.g. on a box without a GPU")
+    ap.add_argument("--c5-images", type=int, default=None, help="image count of the c5 extra block (default: the named 10000)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a one-GPU box: all ranks use cuda:0 and rendezvous over gloo (not a measurement)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: this process starts the ranks and touches no GPU itself (torch is not even imported here)
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.dry_run:
+        sys.exit(dry_run(args))
 
     from cameracalibrations_amd import synthetic as syn
     from cameracalibrations_amd.solver import CRITERIA
@@ -508,6 +656,7 @@ def main():
     # like for like with OpenCV's loop (and the CPU baseline): sweeps at new candidate points count; the re-damping
     # sweeps a rejected step costs THIS design are not counted as work, only their time is
     sweeps = r["sweeps"] * args.steps
+    eager_elapsed = job.eager_solves(s, args.steps, min(args.warmup, 5))
     sweep_us, n_timed, sweep_us_b2b, ev_s = job.launch_timing(s, args.steps)
 
     # closed-form init and a full fit, reported separately
@@ -546,6 +695,12 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            # what a step costs beyond its kernels: the step's wall time minus the summed device time of every launch of one
+            # solve (HIP events bound to the dispatches, from the event-instrumented pass) = graph replay, inter-kernel
+            # boundaries and the host's wait; and the same solves launched kernel by kernel instead of as one graph
+            "host_overhead_us_per_step": 1e6 * elapsed / args.steps - job.solve_kernels_us,
+            "solve_kernels_us_per_step": job.solve_kernels_us,
+            "eager_ms_per_step": 1e3 * eager_elapsed / args.steps,
             "higher_is_better": True,
             # the 1/2/4/8-GPU series is ONE 1000-image problem (configs[2] on one GPU, configs[3] sharded): total work fixed
             "scaling": "strong" if (strong or world == 1) else "weak",
@@ -565,15 +720,12 @@ def main():
 
     # ---- extra blocks (never `value`) ---------------------------------------------------------------------
     extras = not (args.no_extras or args.timed_only)
-    # A rehearsal (--share-gpu) puts every rank's kernels on ONE GPU, and they wait for each other's rows: all ranks'
-    # workgroups must be resident together (256 CUs, one or two of these workgroups each), so the extra blocks are kept
-    # to 256 workgroups in total there.  A real run has one GPU per rank and uses the named sizes.
-    rehearsal_cap = 4 * (256 // world) if (args.share_gpu and world > 1) else 0
+    # Every stage of an extra block that can fail on one rank alone ends in an agreement of all ranks (Job.together):
+    # either all of them go on or all of them raise BlockFailed at the same point and skip the block together.
     steps_x, warm_x = max(5, min(args.steps, 50)), 5
     if extras and world > 1 and strong and args.workload in ("C2", "C3"):
         try:
-            wlw = syn.named_workload(args.workload, n_images=(min(args.images or 1000, rehearsal_cap) if rehearsal_cap else args.images),
-                                     seed_offset=1000 * rank)
+            wlw = job.together(lambda: syn.named_workload(args.workload, n_images=args.images, seed_offset=1000 * rank), "weak-scaling data")
             sw, _, comm_w = job.make_solver(wlw, wlw.img, wlw.n_images * world, CRITERIA)
             el, rw = job.timed_solves(sw, steps_x, warm_x)
             if rank == 0:
@@ -584,12 +736,12 @@ def main():
                                        "lm": lm_block(rw)}
             sw.close()
             del sw
-        except Exception as exc:      # noqa: BLE001
+        except BlockFailed as exc:    # (raised by every rank together)
             if rank == 0:
                 out["weak_scaling"] = {"error": str(exc)}
     if extras and args.workload != "C5":
         try:
-            wl5 = syn.named_workload("C5", n_images=(rehearsal_cap * world if rehearsal_cap else None))
+            wl5 = job.together(lambda: syn.named_workload("C5", n_images=args.c5_images), "C5 data")
             my5 = shard(wl5, world, rank)
             s5, _, comm5 = job.make_solver(wl5, my5, wl5.n_images, CRITERIA)
             st5 = max(5, min(args.steps, 20))
@@ -605,7 +757,7 @@ def main():
                                                                                                  "true" if my5.shape[0] > 2048 else "false"))}
             s5.close()
             del s5
-        except Exception as exc:      # noqa: BLE001
+        except BlockFailed as exc:    # (raised by every rank together)
             if rank == 0:
                 out["c5"] = {"error": str(exc)}
     if extras and world == 1:

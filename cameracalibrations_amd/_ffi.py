@@ -40,7 +40,7 @@ class Stats(C.Structure):
                 ("t_init_intr_s", C.c_double), ("t_init_extr_s", C.c_double), ("t_lm_s", C.c_double),
                 ("iters", C.c_int32), ("sweeps", C.c_int32), ("reschur", C.c_int32), ("rejected", C.c_int32),
                 ("lambda_lg10", C.c_int32), ("n_bad", C.c_int32), ("timed_sweeps", C.c_int32), ("pad_", C.c_int32),
-                ("sweep_us", C.c_double)]
+                ("sweep_us", C.c_double), ("solve_kernels_us", C.c_double)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -70,6 +70,8 @@ SIGNATURES = {
     "ccal_p2p_export": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),
     "ccal_p2p_connect": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "ccal_p2p_selftest": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ccal_p2p_set_exchange": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ccal_device_uuid": (C.c_int, [C.c_int32, C.c_char_p]),
     "ccal_set_problem": (C.c_int, [C.c_void_p, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double,
                                    C.c_uint32, C.c_int32, C.c_double]),
     "ccal_set_image_points": (C.c_int, [C.c_void_p, _fp]),
@@ -80,6 +82,7 @@ SIGNATURES = {
     "ccal_set_extrinsics": (C.c_int, [C.c_void_p, _dp]),
     "ccal_lm_run": (C.c_int, [C.c_void_p]),
     "ccal_set_sweep_timing": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ccal_set_graph": (C.c_int, [C.c_void_p, C.c_int32]),
     "ccal_get_result": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.POINTER(Stats)]),
     "ccal_get_trace": (C.c_int, [C.c_void_p, C.POINTER(Trace), C.c_int32, C.POINTER(C.c_int32)]),
     "ccal_calibrate": (C.c_int, [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_uint32,

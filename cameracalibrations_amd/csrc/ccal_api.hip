@@ -96,13 +96,16 @@ struct ccal_ctx {
     int world = 1, rank = 0;
     Comm *comm = nullptr;              // native RCCL communicator (ccal_comm_init_rank)
     P2P *p2p = nullptr;                // direct xGMI row exchange (ccal_p2p_export / ccal_p2p_connect)
+    bool p2p_no_fuse = false;          // ranks of several processes share this GPU: one-workgroup exchange, never whole grids polling
+    bool p2p_split = false;            // shards of one host thread share this GPU AND its stream: send / receive as two kernels
     Detector *detector = nullptr;      // corner detector buffers (ccal_detect_corners)
     int64_t n_global = 0;
     int lm_batch = 8;
     // optional per-sweep event timing
     bool time_sweeps = false;
-    std::vector<hipEvent_t> ev;   // 2 * MAX_KINDS events, created on demand
+    std::vector<hipEvent_t> ev;   // 2 * MAX_KINDS events (+ one pair for the terminating launch), created on demand
     int ev_used = 0;
+    bool ev_final_used = false;
     // one solve = one replayable graph: begin + lm_batch x (sweep, solve) + state read-back
     hipGraphExec_t g_first = nullptr;
     struct GraphKey {             // everything baked into the captured launches
@@ -127,9 +130,6 @@ static void free_problem_buffers(ccal_ctx *c) {
     c->d_H = c->d_foc_partials = c->d_gram = nullptr;
     c->img_cap = 0; c->n_cap = 0; c->p_cap = 0;
 }
-
-static thread_local bool t_stream_priority_set = false;
-static thread_local int t_stream_priority = 0;
 
 extern "C" {
 
@@ -162,14 +162,7 @@ int ccal_create(int device, ccal_ctx **out) {
     HIPCHK(hipSetDevice(device));
     ccal_ctx *c = new ccal_ctx();
     c->device = device;
-    if (t_stream_priority_set) {
-        // ccal_calibrate_multi with one device listed more than once: the shards' kernels wait for each
-        // other, so their streams must not end up in the same hardware queue (a queue runs in order);
-        // streams of different priority never share one
-        HIPCHK(hipStreamCreateWithPriority(&c->own_stream, hipStreamNonBlocking, t_stream_priority));
-    } else {
-        HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
-    }
+    HIPCHK(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIPCHK(hipMalloc(&c->d_st, sizeof(LmState) * 2));          // S_k lives in d_st[k & 1]
     HIPCHK(hipMalloc(&c->d_st_scratch, sizeof(LmState) * 2));
@@ -336,6 +329,25 @@ int ccal_p2p_selftest(ccal_ctx *c, int32_t rounds) {
     std::string err;
     if (c->p2p->check_and_clear(err)) return fail(CCAL_E_COMM, "ccal_p2p_selftest: " + err);
     if (bad) return fail(CCAL_E_COMM, "ccal_p2p_selftest: exchanged sums differ from the expected values");
+    return CCAL_OK;
+}
+
+int ccal_p2p_set_exchange(ccal_ctx *c, int32_t mode) {
+    if (!c) return fail(CCAL_E_ARG, "ccal_p2p_set_exchange: ctx == NULL");
+    if (mode != 0 && mode != 1) return fail(CCAL_E_ARG, "ccal_p2p_set_exchange: mode is 0 (automatic) or 1 (one-workgroup exchange)");
+    c->p2p_no_fuse = mode == 1;
+    c->graph_dirty = true;             // a captured solve holds the launches of the old mode
+    return CCAL_OK;
+}
+
+int ccal_device_uuid(int32_t device, char uuid_out[16]) {
+    if (!uuid_out) return fail(CCAL_E_ARG, "ccal_device_uuid: NULL argument");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return fail(CCAL_E_ARG, "ccal_device_uuid: bad device index");
+    hipUUID id;
+    HIPCHK(hipDeviceGetUuid(&id, device));
+    static_assert(sizeof id.bytes == 16, "uuid size");
+    memcpy(uuid_out, id.bytes, 16);
     return CCAL_OK;
 }
 
@@ -534,33 +546,47 @@ static int finish_init(ccal_ctx *c, bool intr, bool extr) {
     return finish_init_check(c, intr, extr);
 }
 
-int ccal_init_intrinsics(ccal_ctx *c) {
+// A4 in two halves, so that shards sharing one in-order stream (p2p_split) can put every shard's send in front
+// of every shard's receive:  a = homographies + local focal sums (+ send),  b = (receive | all-reduce) + 2x2 solve
+static int init_intrinsics_a(ccal_ctx *c) {
     if (!c) return fail(CCAL_E_ARG, "ccal_init_intrinsics: ctx == NULL");
     if (!c->have_problem || !c->have_img) return fail(CCAL_E_STATE, "ccal_init_intrinsics: problem/image points not set");
     if (!c->planar_z0)
         return fail(CCAL_E_NONPLANAR, "For non-planar calibration rigs the initial intrinsic matrix must be specified");
     HIPCHK(hipSetDevice(c->device));
-    const double t0 = now_s();
+    c->run_t0 = now_s();
     HIPCHK(launch_init_homography(c->stream, c->d_obj, c->d_img, c->d_H, c->d_foc_partials, c->N, c->P, c->width,
                                   c->height));
+    if (sharded(c)) {
+        HIPCHK(launch_init_focal_reduce(c->stream, c->d_foc_partials, c->d_foc_red, c->N));
+        if (via_p2p(c) && c->p2p_split) HIPCHK(launch_p2p_send(c->stream, c->p2p->dev(), c->d_foc_red, NFOC));
+    }
+    return CCAL_OK;
+}
+
+static int init_intrinsics_b(ccal_ctx *c) {
+    HIPCHK(hipSetDevice(c->device));
     const double aspect = (c->flags & CCAL_FIX_ASPECT_RATIO) ? c->aspect : 0.0;
     int rc = CCAL_OK;
-    const bool exchange = via_p2p(c) || (c->comm && c->comm->ready()) || c->ar_fn;
-    if (!exchange) {
+    if (!sharded(c)) {
         // this GPU holds every image: sums and the 2x2 solve in one launch
         HIPCHK(launch_init_focal_reduce_solve(c->stream, c->d_foc_partials, c->d_foc_red, c->N, c->d_intr0, c->d_fail, c->width,
                                               c->height, aspect));
     } else {
-        HIPCHK(launch_init_focal_reduce(c->stream, c->d_foc_partials, c->d_foc_red, c->N));
-        rc = run_allreduce(c, c->d_foc_red, NFOC);
-        if (rc) return rc;
+        if (via_p2p(c) && c->p2p_split) HIPCHK(launch_p2p_recv(c->stream, c->p2p->dev(), c->d_foc_red, NFOC));
+        else if ((rc = run_allreduce(c, c->d_foc_red, NFOC)) != CCAL_OK) return rc;
         HIPCHK(launch_init_focal_solve(c->stream, c->d_foc_red, c->d_intr0, c->d_fail, c->width, c->height, aspect));
     }
     if (!c->defer_sync && (rc = finish_init(c, true, false)) != CCAL_OK) return rc;
     c->have_intr = true;
     c->have_result = false;
-    c->stats.t_init_intr_s = now_s() - t0;
+    c->stats.t_init_intr_s = now_s() - c->run_t0;
     return CCAL_OK;
+}
+
+int ccal_init_intrinsics(ccal_ctx *c) {
+    const int rc = init_intrinsics_a(c);
+    return rc ? rc : init_intrinsics_b(c);
 }
 
 int ccal_init_extrinsics(ccal_ctx *c) {
@@ -619,6 +645,7 @@ static TrialLaunch base_launch(ccal_ctx *c) {
 
 // the exchange is fused into the trial's prologue unless the ranks of this fit run many workgroups each
 static bool xchg_fused(const ccal_ctx *c) {
+    if (c->p2p_no_fuse) return false;  // other processes' ranks share this GPU: a waiting rank must hold one CU, not a grid
     const int64_t ng = c->n_global > 0 ? c->n_global : c->N;
     const int64_t per_rank = (ng + c->world - 1) / (c->world > 0 ? c->world : 1);
     return lm_sweep_blocks((int)per_rank) <= FUSED_XCHG_MAX_BLOCKS;
@@ -635,7 +662,11 @@ static int enqueue_trial(ccal_ctx *c, hipStream_t stream, int k, bool final_only
     if (via_p2p(c)) t.p2p = &c->p2p->dev();
     if (k > 0) {
         if (via_p2p(c)) {
-            if (xchg_fused(c)) {
+            if (c->p2p_split) {
+                // this shard's row was sent by enqueue_send(k), like every other shard's of this stream: collect them
+                HIPCHK(launch_lm_recv(stream, c->d_st, c->d_red, c->p2p->dev(), k));
+                t.row_in = c->d_red;
+            } else if (xchg_fused(c)) {
                 t.xchg_fused = 1;      // the prologue decodes the local row and exchanges it itself
             } else {
                 // one launch: local row, exchange with the peers over xGMI, sum in rank order
@@ -654,8 +685,18 @@ static int enqueue_trial(ccal_ctx *c, hipStream_t stream, int k, bool final_only
         t.ev_start = c->ev[2 * c->ev_used];
         t.ev_stop = c->ev[2 * c->ev_used + 1];
         c->ev_used++;
+    } else if (final_only && c->time_sweeps) {      // (the last terminating launch of a solve is the one that counts)
+        t.ev_start = c->ev[2 * MAX_KINDS];
+        t.ev_stop = c->ev[2 * MAX_KINDS + 1];
+        c->ev_final_used = true;
     }
     HIPCHK(launch_lm_trial(stream, t));
+    return CCAL_OK;
+}
+
+// p2p_split only: the first half of exchange k (every shard of a stream sends before any of them receives)
+static int enqueue_send(ccal_ctx *c, hipStream_t stream, int k) {
+    if (k > 0 && via_p2p(c) && c->p2p_split) HIPCHK(launch_lm_send(stream, c->d_acc, c->acc_R, c->d_st, c->p2p->dev(), k));
     return CCAL_OK;
 }
 
@@ -682,7 +723,7 @@ static int capture_graph(ccal_ctx *c, hipGraphExec_t *out) {
 //   lm_wait    until the batch has been consumed or the solve has ended
 //   lm_more    the graph was sized for another problem: another batch
 //   lm_end     books, errors, size of the next graph
-static int lm_begin(ccal_ctx *c) {
+static int lm_prepare(ccal_ctx *c) {
     if (!c) return fail(CCAL_E_ARG, "ccal_lm_run: ctx == NULL");
     if (!c->have_problem || !c->have_img || !c->have_intr || !c->have_ext)
         return fail(CCAL_E_STATE, "ccal_lm_run: initial intrinsics / extrinsics / image points not set");
@@ -694,6 +735,7 @@ static int lm_begin(ccal_ctx *c) {
     if (via_p2p(c) && c->run_max_trials > 65000L) c->run_max_trials = 65000L;   // the exchange tag carries the trial index in 16 bits
     c->run_trials = 0;
     c->ev_used = 0;
+    c->ev_final_used = false;
     c->h_st->done = 0;
     *progress_word(c) = 0ull;
     if (c->acc_dirty) {
@@ -702,6 +744,15 @@ static int lm_begin(ccal_ctx *c) {
         HIPCHK(hipMemsetAsync(c->d_acc, 0, ACC_BYTES, c->stream));
     }
     c->acc_dirty = true;               // until this solve is seen to have ended with its terminating launch
+    c->run_graphed = false;
+    return CCAL_OK;
+}
+
+static int lm_begin(ccal_ctx *c) {
+    int rc0 = lm_prepare(c);
+    if (rc0) return rc0;
+    if (via_p2p(c) && c->p2p_split)
+        return fail(CCAL_E_STATE, "ccal_lm_run: this context shares its stream with other shards (ccal_calibrate_multi drives it)");
     c->run_graphed = c->use_graph && !c->time_sweeps && (!sharded(c) || via_p2p(c));
     if (c->run_graphed) {
         ccal_ctx::GraphKey key;
@@ -768,18 +819,26 @@ static int lm_end(ccal_ctx *c) {
     c->stats.rms = std::sqrt(r.prev_err / ((double)r.N_global * (double)c->P));
     c->stats.sweep_us = 0.0;
     c->stats.timed_sweeps = 0;
+    c->stats.solve_kernels_us = 0.0;
     if (!r.done) return fail(CCAL_E_STATE, "ccal_lm_run: trial budget exhausted without termination");
     if (c->time_sweeps) {
         HIPCHK(hipStreamSynchronize(c->stream));
-        double sum_ms = 0.0;
+        double sum_ms = 0.0, all_ms = 0.0;
         int n = 0;
         for (int t = 0; t < c->ev_used; t++) {
-            if (r.kinds[t] != 1 + MODE_INIT && r.kinds[t] != 1 + MODE_EVAL) continue;   // re-damping / surplus launches
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * t], c->ev[2 * t + 1]));
+            all_ms += ms;
+            if (r.kinds[t] != 1 + MODE_INIT && r.kinds[t] != 1 + MODE_EVAL) continue;   // re-damping / surplus launches
             sum_ms += ms;
             n++;
         }
+        if (c->ev_final_used) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, c->ev[2 * MAX_KINDS], c->ev[2 * MAX_KINDS + 1]));
+            all_ms += ms;
+        }
+        c->stats.solve_kernels_us = 1000.0 * all_ms;
         c->stats.timed_sweeps = n;
         c->stats.sweep_us = n ? 1000.0 * sum_ms / n : 0.0;
     }
@@ -806,11 +865,17 @@ int ccal_lm_run(ccal_ctx *c) {
     return lm_end(c);
 }
 
+int ccal_set_graph(ccal_ctx *c, int32_t enable) {
+    if (!c) return fail(CCAL_E_ARG, "ccal_set_graph: ctx == NULL");
+    c->use_graph = enable != 0;
+    return CCAL_OK;
+}
+
 int ccal_set_sweep_timing(ccal_ctx *c, int32_t enable) {
     if (!c) return fail(CCAL_E_ARG, "ccal_set_sweep_timing: ctx == NULL");
     HIPCHK(hipSetDevice(c->device));
     if (enable && c->ev.empty()) {
-        c->ev.resize(2 * MAX_KINDS);
+        c->ev.resize(2 * MAX_KINDS + 2);
         for (auto &e : c->ev) HIPCHK(hipEventCreate(&e));
     }
     c->time_sweeps = enable != 0;
@@ -891,6 +956,7 @@ static thread_local ccal_ctx *t_cached[16] = {nullptr};
 struct MultiSet {
     std::vector<int> devices;
     std::vector<ccal_ctx *> ctx;
+    bool shared = false;               // some device carries more than one shard (one stream per device, split exchange)
 };
 static thread_local std::vector<MultiSet> t_multi;
 
@@ -898,6 +964,8 @@ static void multi_destroy(MultiSet &m) {
     // every inbox stays mapped until no context of the set can still be sending
     for (ccal_ctx *c : m.ctx)
         if (c) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); }
+    for (ccal_ctx *c : m.ctx)
+        if (c) c->stream = c->own_stream;          // (shards of one device shared the first one's stream)
     for (ccal_ctx *c : m.ctx)
         if (c) ccal_destroy(c);
     m.ctx.clear();
@@ -993,22 +1061,19 @@ static MultiSet *multi_get(int n_dev, const int32_t *dev_ids) {
     m.devices = want;
     m.ctx.assign(n_dev, nullptr);
     bool ok = true;
+    // A device listed more than once carries several shards.  Their kernels wait for each other's rows, and a kernel
+    // that waits must never sit in front of the kernel that sends in an in-order hardware queue (streams of one
+    // process may share one): all shards of a device therefore run on ONE stream, and the exchange is split into a
+    // send and a receive kernel, every shard's send enqueued before any shard's receive (k_lm_send / k_lm_recv).
+    // Nothing then waits for anything that is queued behind it, whatever the number of shards.
+    for (int g = 0; g < n_dev; g++)
+        for (int h = 0; h < g; h++) m.shared = m.shared || dev_ids[h] == dev_ids[g];
     for (int g = 0; g < n_dev && ok; g++) {
-        int dup = 0;
-        for (int h = 0; h < g; h++) dup += dev_ids[h] == dev_ids[g];
-        if (dup > 0) {
-            int least = 0, greatest = 0;
-            ok = hipSetDevice(dev_ids[g]) == hipSuccess && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
-            if (!ok || dup > 2 || least == greatest) {
-                fail(CCAL_E_ARG, "ccal_calibrate_multi: a device can be listed at most three times (one stream priority each)");
-                ok = false;
-                break;
-            }
-            t_stream_priority_set = true;
-            t_stream_priority = dup == 1 ? greatest : least;
-        }
         ok = ccal_create(dev_ids[g], &m.ctx[g]) == CCAL_OK;
-        t_stream_priority_set = false;
+        if (!ok) break;
+        m.ctx[g]->p2p_split = m.shared;
+        for (int h = 0; h < g; h++)
+            if (dev_ids[h] == dev_ids[g]) { m.ctx[g]->stream = m.ctx[h]->stream; break; }
     }
     std::vector<P2P *> boxes(n_dev, nullptr);
     std::string err;
@@ -1035,6 +1100,25 @@ static MultiSet *multi_get(int n_dev, const int32_t *dev_ids) {
     t_multi.push_back(m);
     (void)&t_cache_guard;
     return &t_multi.back();
+}
+
+// shared-device sets: trials k0 .. k0 + count - 1 of EVERY shard plus the terminating prologue-only launch, trial by
+// trial -- first every shard's send of exchange k, then every shard's receive + trial k (see multi_get)
+static int multi_enqueue(MultiSet *m, int k0, int count) {
+    int rc = CCAL_OK;
+    for (int k = k0; k <= k0 + count && rc == CCAL_OK; k++) {
+        const bool final_only = k == k0 + count;
+        for (ccal_ctx *c : m->ctx) {
+            HIPCHK(hipSetDevice(c->device));
+            if ((rc = enqueue_send(c, c->stream, k)) != CCAL_OK) return rc;
+        }
+        for (ccal_ctx *c : m->ctx) {
+            HIPCHK(hipSetDevice(c->device));
+            if ((rc = enqueue_trial(c, c->stream, k, final_only)) != CCAL_OK) return rc;
+        }
+    }
+    for (ccal_ctx *c : m->ctx) c->run_trials = k0 + count;
+    return rc;
 }
 
 int ccal_calibrate_multi(const float *obj, const float *img, int32_t P, int32_t N, int32_t width, int32_t height,
@@ -1068,13 +1152,25 @@ int ccal_calibrate_multi(const float *obj, const float *img, int32_t P, int32_t 
             }
         }
         if (rc < 0) break;
-        if (!guess)
-            for (int g = 0; g < n_dev && rc >= 0; g++) rc = ccal_init_intrinsics(m->ctx[g]);
+        if (!guess) {
+            for (int g = 0; g < n_dev && rc >= 0; g++) rc = init_intrinsics_a(m->ctx[g]);
+            for (int g = 0; g < n_dev && rc >= 0; g++) rc = init_intrinsics_b(m->ctx[g]);
+        }
         for (int g = 0; g < n_dev && rc >= 0; g++) rc = ccal_init_extrinsics(m->ctx[g]);
-        for (int g = 0; g < n_dev && rc >= 0; g++) rc = lm_begin(m->ctx[g]);
+        if (m->shared) {
+            // trial by trial over all shards: sends of exchange k, then (receive, trial k) of every shard
+            for (int g = 0; g < n_dev && rc >= 0; g++) rc = lm_prepare(m->ctx[g]);
+            if (rc >= 0) rc = multi_enqueue(m, 0, m->ctx[0]->lm_batch);
+        } else {
+            for (int g = 0; g < n_dev && rc >= 0; g++) rc = lm_begin(m->ctx[g]);
+        }
         for (int g = 0; g < n_dev && rc >= 0; g++) rc = lm_wait(m->ctx[g]);
         while (rc >= 0 && lm_unfinished(m->ctx[0])) {   // identical state on every device: one decision for all
-            for (int g = 0; g < n_dev && rc >= 0; g++) rc = lm_more(m->ctx[g]);
+            if (m->shared) {
+                rc = multi_enqueue(m, (int)m->ctx[0]->run_trials, m->ctx[0]->lm_batch < 4 ? 4 : m->ctx[0]->lm_batch);
+            } else {
+                for (int g = 0; g < n_dev && rc >= 0; g++) rc = lm_more(m->ctx[g]);
+            }
             for (int g = 0; g < n_dev && rc >= 0; g++) rc = lm_wait(m->ctx[g]);
         }
         if (rc < 0) break;

@@ -40,6 +40,9 @@ hipError_t launch_lm_row(hipStream_t stream, const long long *acc, int R, const 
 // exchange -> out[0..68), as exchange k of the current solve (few workgroups: fused into k_lm_trial)
 hipError_t launch_lm_exchange(hipStream_t stream, const long long *acc, int R, const LmState *st, double *out, const P2PDev &p,
                               int k);
+// the same exchange as two stream-ordered kernels (shards sharing one in-order stream: all sends before any receive)
+hipError_t launch_lm_send(hipStream_t stream, const long long *acc, int R, const LmState *st, const P2PDev &p, int k);
+hipError_t launch_lm_recv(hipStream_t stream, const LmState *st, double *out, const P2PDev &p, int k);
 
 // ccal_init.hip -- closed-form initialisation
 constexpr int NFOC = 8;   // doubles all-reduced for the focal least squares: AtA(3) Atb(2) fail(1) pad(2)

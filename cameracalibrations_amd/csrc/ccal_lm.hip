@@ -10,7 +10,7 @@
 //                22 KB at R = 8 -- not one row per workgroup), turned back into 68 doubles, and wave 0
 //                advances the CvLevMarq state machine on an LDS copy of the state: accept / reject,
 //                lambda schedule, stop rule, and the 9x9 damped Schur system for this trial's step,
-//                factored with one matrix row per lane (v_readlane broadcasts of the pivot column).
+//                solved with one matrix row per lane (scaled Gauss-Jordan, pivot row broadcast by DPP row_newbcast).
 //                Workgroup 0 persists the state (double-buffered by trial parity) and reports to the
 //                host.  Then the sweep: one 64-lane wavefront per image, one lane per corner.
 //                  1. back-substitute this image's extrinsic step from the factor stored by the
@@ -23,7 +23,10 @@
 //                     into acc[k % 3][blockIdx % R] (ccal_acc.hpp: exact, order-independent)
 //   k_lm_row     only when a collective library sums the system across GPUs (RCCL / host hook):
 //                accumulators -> one row of 68 doubles.
-//   k_lm_exchange  multi-GPU with many workgroups: accumulators -> one row -> direct xGMI exchange.
+//   k_lm_exchange  multi-GPU with many workgroups, or ranks of several processes sharing one GPU: accumulators ->
+//                one row -> direct xGMI exchange, by ONE workgroup (a waiting rank then holds one CU, not a grid).
+//   k_lm_send / k_lm_recv  the same exchange in two stream-ordered halves for shards that share one in-order
+//                stream (ccal_calibrate_multi with a device listed more than once).
 //
 // A solve of T trials is T + 1 launches of k_lm_trial (the last one runs the prologue only and
 // leaves the accumulators cleared for the next solve).
@@ -972,6 +975,39 @@ __global__ __launch_bounds__(WAVES * 64) void k_lm_exchange(const long long *__r
 }
 
 // ---------------------------------------------------------------------------------------
+// The same exchange as two kernels, for shards of one fit that share a device (one in-order stream): every
+// shard's k_lm_send is enqueued before any shard's k_lm_recv, so nothing that waits ever sits in front of what
+// it waits for (ccal_p2p_dev.hpp).  k_lm_send: accumulators -> row -> every inbox, the own one included;
+// k_lm_recv: all rows of exchange k -> sum in rank order -> out[0..68).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WAVES * 64) void k_lm_send(const long long *__restrict__ acc, int R, const LmState *__restrict__ st,
+                                                         P2PDev p, int k) {
+    __shared__ AccPart s_acc[ACC_ROW];
+    __shared__ double s_val[NRED];
+    const int tid = threadIdx.x;
+    if (__hip_atomic_load(&st[(k - 1) & 1].done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    AccRegs q;
+    acc_read_issue(acc + (size_t)((k + 2) % 3) * R * ACC_ROW, R, tid, q);
+    acc_read_stage(acc + (size_t)((k + 2) % 3) * R * ACC_ROW, R, s_acc, tid, q);
+    __syncthreads();
+    if (tid < NRED) s_val[tid] = acc_row_decode(s_acc, tid);
+    __syncthreads();
+    const unsigned int seq = __hip_atomic_load(p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p2p_send_row(p, p2p_tag(seq, (unsigned)k), p2p_slot(seq, (unsigned)k), s_val, NRED, tid);
+}
+
+__global__ __launch_bounds__(WAVES * 64) void k_lm_recv(const LmState *__restrict__ st, double *__restrict__ out, P2PDev p, int k) {
+    __shared__ double s_val[NRED];
+    __shared__ double s_all[P2P_MAX_RANKS * NRED];
+    const int tid = threadIdx.x;
+    if (__hip_atomic_load(&st[(k - 1) & 1].done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    if (__hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) return;   // a peer already timed out
+    const unsigned int seq = __hip_atomic_load(p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    p2p_recv_rows(p, p2p_tag(seq, (unsigned)k), p2p_slot(seq, (unsigned)k), s_val, s_all, NRED, tid);
+    if (tid < NRED) out[tid] = s_val[tid];
+}
+
+// ---------------------------------------------------------------------------------------
 // diagnostics: the exact accumulators on their own (ccal_debug_acc_sum).  "Workgroup" b adds its row of
 // 68 doubles into replica b mod R exactly as a sweep does; one workgroup then reads and decodes the sums
 // exactly as a trial's prologue does.
@@ -1065,6 +1101,16 @@ hipError_t launch_lm_row(hipStream_t stream, const long long *acc, int R, const 
 hipError_t launch_lm_exchange(hipStream_t stream, const long long *acc, int R, const LmState *st, double *out, const P2PDev &p,
                               int k) {
     hipLaunchKernelGGL(k_lm_exchange, dim3(1), dim3(WAVES * 64), 0, stream, acc, R, st, out, p, k);
+    return hipGetLastError();
+}
+
+hipError_t launch_lm_send(hipStream_t stream, const long long *acc, int R, const LmState *st, const P2PDev &p, int k) {
+    hipLaunchKernelGGL(k_lm_send, dim3(1), dim3(WAVES * 64), 0, stream, acc, R, st, p, k);
+    return hipGetLastError();
+}
+
+hipError_t launch_lm_recv(hipStream_t stream, const LmState *st, double *out, const P2PDev &p, int k) {
+    hipLaunchKernelGGL(k_lm_recv, dim3(1), dim3(WAVES * 64), 0, stream, st, out, p, k);
     return hipGetLastError();
 }
 

@@ -117,6 +117,39 @@ __global__ __launch_bounds__(256) void k_p2p_allreduce(P2PDev p, double *buf, in
     if (tid < n) buf[tid] = s_val[tid];
 }
 
+// the stand-alone all-reduce in two stream-ordered halves (shards sharing one in-order queue, ccal_p2p_dev.hpp):
+// the send takes the next sequence number without publishing it, the receive publishes it
+__global__ __launch_bounds__(256) void k_p2p_send(P2PDev p, const double *buf, int n) {
+    __shared__ double s_val[P2P_MAX_DOUBLES];
+    const int tid = threadIdx.x;
+    if (tid < n) s_val[tid] = buf[tid];
+    __syncthreads();
+    const unsigned int seq = __hip_atomic_load(p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    p2p_send_row(p, p2p_tag(seq, 0), p2p_slot(seq, 0), s_val, n, tid);
+}
+
+__global__ __launch_bounds__(256) void k_p2p_recv(P2PDev p, double *buf, int n) {
+    __shared__ double s_val[P2P_MAX_DOUBLES];
+    __shared__ double s_all[P2P_MAX_RANKS * P2P_MAX_DOUBLES];
+    const int tid = threadIdx.x;
+    const unsigned int seq = __hip_atomic_load(p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    p2p_recv_rows(p, p2p_tag(seq, 0), p2p_slot(seq, 0), s_val, s_all, n, tid);
+    if (tid < n) buf[tid] = s_val[tid];
+    if (tid == 0) __hip_atomic_store(p.epoch, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+hipError_t launch_p2p_send(hipStream_t stream, const P2PDev &p, const double *buf, int n) {
+    if (n < 1 || n > P2P_MAX_DOUBLES) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_p2p_send, dim3(1), dim3(256), 0, stream, p, buf, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_p2p_recv(hipStream_t stream, const P2PDev &p, double *buf, int n) {
+    if (n < 1 || n > P2P_MAX_DOUBLES) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_p2p_recv, dim3(1), dim3(256), 0, stream, p, buf, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_p2p_allreduce(hipStream_t stream, const P2PDev &p, double *buf, int n) {
     if (n < 1 || n > P2P_MAX_DOUBLES) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(256), 0, stream, p, buf, n);

@@ -72,5 +72,9 @@ class P2P {
 
 // buf[0..n) <- sum over ranks (n <= 68), one workgroup on `stream`
 hipError_t launch_p2p_allreduce(hipStream_t stream, const P2PDev &p, double *buf, int n);
+// the same all-reduce as two kernels, for ranks whose kernels share one in-order queue: every such rank's send is
+// enqueued before any of their receives (a kernel that waits must never sit in front of the kernel that sends)
+hipError_t launch_p2p_send(hipStream_t stream, const P2PDev &p, const double *buf, int n);
+hipError_t launch_p2p_recv(hipStream_t stream, const P2PDev &p, double *buf, int n);
 
 }  // namespace ccal

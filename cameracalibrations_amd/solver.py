@@ -18,6 +18,7 @@ class Solver:
 
     def __init__(self, device=0, stream=None):
         self._h = C.c_void_p()
+        self.device = int(device)
         F.check(F.lib().ccal_create(int(device), C.byref(self._h)))
         self._keep = []          # arrays / callbacks that must outlive the device work
         self.N = self.P = 0
@@ -69,18 +70,27 @@ class Solver:
         assert len(ident) == 128
         F.check(F.lib().ccal_comm_init_rank(self._h, int(world_size), int(rank), ident, int(n_images_global)))
 
-    def init_p2p(self, world_size, rank, n_images_global, allgather_bytes):
+    def init_p2p(self, world_size, rank, n_images_global, allgather_bytes, shared_device=None):
         """Direct xGMI row exchange between the GPUs of one node (no collective library).
-        `allgather_bytes(b: bytes) -> list[bytes]` returns every rank's 64-byte inbox handle in
-        rank order (e.g. through torch.distributed)."""
-        buf = C.create_string_buffer(64)
+        `allgather_bytes(b: bytes) -> list[bytes]` returns every rank's bytes in rank order (e.g. through
+        torch.distributed): the 64-byte inbox handle followed by the 16-byte id of the rank's device.  Two ranks
+        with the same device id share a GPU (a rehearsal on a one-GPU box): every rank then takes the
+        one-workgroup exchange (ccal_p2p_set_exchange), so that a waiting rank holds one compute unit and not a
+        grid; `shared_device` forces the answer.  Returns True when a device is shared."""
+        buf, uid = C.create_string_buffer(64), C.create_string_buffer(16)
         rc = F.lib().ccal_p2p_export(self._h, int(world_size), int(rank), buf)
-        handles = allgather_bytes(buf.raw if rc == 0 else bytes(64))   # the gather is collective: always join it
+        if rc == 0:
+            rc = F.lib().ccal_device_uuid(int(self.device), uid)
+        got = allgather_bytes(buf.raw + uid.raw if rc == 0 else bytes(80))   # the gather is collective: always join it
         F.check(rc)
-        assert len(handles) == world_size and all(len(h) == 64 for h in handles)
-        if any(h == bytes(64) for h in handles):
+        assert len(got) == world_size and all(len(h) == 80 for h in got)
+        if any(h[:64] == bytes(64) for h in got):
             raise RuntimeError("init_p2p: a peer rank could not export its inbox")
-        F.check(F.lib().ccal_p2p_connect(self._h, b"".join(handles), int(n_images_global)))
+        ids = [h[64:] for h in got]
+        shared = len(set(ids)) < len(ids) if shared_device is None else bool(shared_device)
+        F.check(F.lib().ccal_p2p_connect(self._h, b"".join(h[:64] for h in got), int(n_images_global)))
+        F.check(F.lib().ccal_p2p_set_exchange(self._h, 1 if shared else 0))
+        return shared
 
     def p2p_selftest(self, rounds=8):
         """Exchanges known rows `rounds` times and checks the sums (all ranks call it together)."""
@@ -128,6 +138,10 @@ class Solver:
 
     def set_sweep_timing(self, enable=True):
         F.check(F.lib().ccal_set_sweep_timing(self._h, int(bool(enable))))
+
+    def set_graph(self, enable=True):
+        """replay a solve as one hipGraph (default) or launch it kernel by kernel"""
+        F.check(F.lib().ccal_set_graph(self._h, int(bool(enable))))
 
     def lm_run(self):
         return F.check(F.lib().ccal_lm_run(self._h))

@@ -78,6 +78,8 @@ typedef struct ccal_stats {
     int32_t timed_sweeps;  /* sweeps covered by sweep_us (0 unless ccal_set_sweep_timing is on) */
     int32_t pad_;
     double sweep_us;       /* mean device time of the sweep kernel, HIP events on the launch stream */
+    double solve_kernels_us; /* device time of ALL launches of the solve (every trial + the terminating one), summed;
+                              * 0 unless ccal_set_sweep_timing is on */
 } ccal_stats;
 
 /* One LM decision, for trajectory parity tests against the oracle. */
@@ -132,6 +134,15 @@ int  ccal_p2p_connect(ccal_ctx *ctx, const char *handles, int64_t n_images_globa
 /* `rounds` exchanges of known rows, checked on the host (every rank must call it with the same
  * count): CCAL_OK, or CCAL_E_COMM when a peer stayed silent or a sum came back wrong. */
 int  ccal_p2p_selftest(ccal_ctx *ctx, int32_t rounds);
+/* How a rank takes part in the exchange.  mode 0 (default): automatic -- fused into the prologue of every
+ * trial's kernel (all its workgroups poll the inbox) while a rank runs few workgroups, one exchange workgroup
+ * per trial otherwise.  mode 1: always the one-workgroup exchange; REQUIRED on every rank when ranks of several
+ * processes share one GPU (rehearsals, time-shared devices): a rank that waits then holds one compute unit
+ * instead of a whole grid that keeps the sender off the chip.  Same wire format either way; call it with the same
+ * value on every rank, before the first solve.  ccal_device_uuid lets the ranks find out (all-gather the 16 bytes
+ * next to the inbox handle; two equal ids = a shared device), as the Python mirror's Solver.init_p2p does. */
+int  ccal_p2p_set_exchange(ccal_ctx *ctx, int32_t mode);
+int  ccal_device_uuid(int32_t device, char uuid_out[16]);
 
 /* ---- problem ------------------------------------------------------------------------ */
 /* Replaces the marshalling of fit_model (src/detect_fit.jl:30-45): template, image size
@@ -154,6 +165,9 @@ int  ccal_init_extrinsics(ccal_ctx *ctx);
 int  ccal_set_extrinsics(ccal_ctx *ctx, const double *rt_host);
 /* A6-A9 global Levenberg-Marquardt with OpenCV's schedule, on the device. */
 int  ccal_lm_run(ccal_ctx *ctx);
+/* A solve is replayed as one hipGraph (default; CCAL_NO_GRAPH=1 in the environment turns that off at ccal_create) or
+ * launched kernel by kernel: same kernels, same results, different host cost. */
+int  ccal_set_graph(ccal_ctx *ctx, int32_t enable);
 /* Bracket every sweep launch of the next ccal_lm_run calls with a HIP event pair on the launch
  * stream and report the mean in ccal_stats.sweep_us (roofline figure of bench.py). */
 int  ccal_set_sweep_timing(ccal_ctx *ctx, int32_t enable);
@@ -176,8 +190,9 @@ int  ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, in
  * the direct xGMI row exchange (the inboxes are plain peer-mapped pointers here, no IPC).  Every stage
  * is enqueued on all devices before the host waits for any.  img / rvecs / tvecs are the full [.,.,N] /
  * [3,N] host arrays; results are identical on every device and taken from dev_ids[0].  1..16 devices,
- * N >= n_dev; a device id may appear up to three times (shards on one GPU, each on a stream of its own
- * priority so that they never share an in-order hardware queue; used by the tests). */
+ * N >= n_dev; a device id may appear more than once (several shards on one GPU -- how a one-GPU box rehearses
+ * 2/4/8-way sharding): all shards of a device then run on ONE stream and the exchange becomes two kernels,
+ * every shard's send enqueued before any shard's receive, so nothing ever waits for work queued behind it. */
 int  ccal_calibrate_multi(const float *obj, const float *img, int32_t P, int32_t N, int32_t width,
                           int32_t height, double aspect, uint32_t flags, int32_t max_iter, double eps,
                           int32_t n_dev, const int32_t *dev_ids, double K4[4], double dist5[5],

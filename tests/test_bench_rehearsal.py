@@ -68,27 +68,23 @@ def test_bench_two_ranks_rehearsal():
 
 @pytest.mark.gpu
 def test_bench_four_ranks_full_c3_rehearsal():
-    """The command the driver runs at N = 4, rehearsed with the ranks sharing the one GPU: the real 1000-image C3 set in
-    four shards, plus the weak-scaling and C5 extra blocks (cut down to what one GPU can hold resident for all ranks)."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, CCAL_P2P_TIMEOUT_MS="8000")
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
-                        "--gpus", "4", "--steps", "10", "--warmup", "2", "--share-gpu"],
-                       capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
+    """The command the driver runs at N = 4 -- `python bench.py --gpus 4`, NO launcher: bench.py starts its own ranks --
+    rehearsed with the ranks sharing the one GPU: the real 1000-image C3 set in four shards, plus the weak-scaling
+    block at its named size (1000 images per rank) and the C5 block (cut to 2048 images to keep the rehearsal short).
+    Ranks that share a GPU exchange through ONE workgroup each (ccal_p2p_set_exchange), so a waiting rank never keeps
+    the sender off the chip: every block must come through the direct exchange, no fallback."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["CCAL_P2P_TIMEOUT_MS"] = "8000"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "10", "--warmup", "2",
+                        "--share-gpu", "--c5-images", "2048"], capture_output=True, text=True, timeout=800, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     d = _last_json(p.stdout)
     assert d["n_gpus"] == 4 and d["scaling"] == "strong" and "configs[3]" in d["config"]["workload"]
     assert d["config"]["images_total"] == 1000 and d["config"]["images_rank0"] == 250
     assert abs(d["lm"]["rms_px"] - 0.13703750955) < 1e-9 and d["lm"]["iters_to_tol_1e-3"] == 4    # = the one-GPU fit
     w = d["weak_scaling"]
-    assert w["config"]["images_total"] == 1024 and w["config"]["images_rank0"] == 256 and 0.12 < w["lm"]["rms_px"] < 0.15
+    assert w["config"]["images_total"] == 4000 and w["config"]["images_rank0"] == 1000 and 0.12 < w["lm"]["rms_px"] < 0.15
     c5 = d["c5"]
-    assert c5["config"]["images_total"] == 1024 and c5["config"]["images_rank0"] == 256 and 0.12 < c5["lm"]["rms_px"] < 0.16
-    for blk in (d, w):
-        assert blk["config"]["allreduce"].startswith("p2p")
-    # (third solver of four processes time-sharing one GPU: whether kernels that wait for each other's rows all get a
-    # hardware queue at once is up to the firmware there, so this block may have fallen back -- collectively -- to the hook)
-    assert c5["config"]["allreduce"].startswith(("p2p", "torch"))
+    assert c5["config"]["images_total"] == 2048 and c5["config"]["images_rank0"] == 512 and 0.12 < c5["lm"]["rms_px"] < 0.16
+    for blk in (d, w, c5):
+        assert blk["config"]["allreduce"].startswith("p2p") and "one exchange workgroup" in blk["config"]["allreduce"]

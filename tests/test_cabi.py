@@ -51,9 +51,32 @@ def test_product_never_imports_oracle():
                 assert "import oracle" not in text and "from oracle" not in text and "ccal_oracle" not in text, f
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors of ccal_stats / ccal_trace against the header itself: gcc compiles include/ccal.h and prints
+    the size of the two structs and the offset of every field."""
+    import shutil
+    import subprocess
     assert C.sizeof(F.Trace) == 32
-    assert C.sizeof(F.Stats) == 6 * 8 + 8 * 4 + 8
+    assert C.sizeof(F.Stats) == 7 * 8 + 8 * 4 + 8
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "layout.c"
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "ccal.h"', 'int main(void) {',
+             'printf("%zu %zu\\n", sizeof(ccal_stats), sizeof(ccal_trace));']
+    for struct, cls in (("ccal_stats", F.Stats), ("ccal_trace", F.Trace)):
+        for name, _ in cls._fields_:
+            lines.append(f'printf("{struct}.{name} %zu\\n", offsetof({struct}, {name}));')
+    lines.append("return 0; }")
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(root, "include"), str(src), "-o", str(exe)])
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    assert out[0].split() == [str(C.sizeof(F.Stats)), str(C.sizeof(F.Trace))]
+    got = dict(ln.split() for ln in out[1:] if ln)
+    for struct, cls in (("ccal_stats", F.Stats), ("ccal_trace", F.Trace)):
+        for name, _ in cls._fields_:
+            assert int(got[f"{struct}.{name}"]) == getattr(cls, name).offset, (struct, name)
 
 
 def test_plain_c_example_compiles_and_links(tmp_path):

@@ -582,12 +582,14 @@ def test_p2p_silent_peer_times_out_instead_of_hanging():
     assert r["seconds"] < 5.0 and "timed out" in r["msg"], r
 
 
-@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0], [0] * 8, [0] * 16])
 def test_calibrate_multi_single_host_thread(devices):
     """ccal_calibrate_multi: one host thread drives one context per listed device (here the test box's
-    one GPU, listed up to three times = up to three shards whose kernels wait for each other's rows through
-    in-process peer pointers).  The joint fit equals the single-context fit of all images, twice in a row
-    (cached contexts, graph replay), and the per-image poses come back in image order."""
+    one GPU, listed up to sixteen times = up to sixteen shards -- the most the exchange carries -- whose rows travel
+    through in-process peer pointers; shards of one device share one stream and exchange by send / receive kernels,
+    every send enqueued before any receive, so nothing waits for work queued behind it).  The joint fit equals the
+    single-context fit of all images, twice in a row (cached contexts), and the per-image poses come back in
+    image order."""
     from cameracalibrations_amd.solver import calibrate_multi
     wl = syn.named_workload("C2", n_images=41)
     with _solver(wl, REF) as s:
@@ -750,6 +752,76 @@ def test_c3_sharded_over_ranks_matches_oracle(world, transport):
     tv = np.vstack([np.array(out[r]["tvecs"]) for r in range(world)])
     assert rv.shape == (1000, 3)
     assert np.abs(rv - ro["rvecs"]).max() < 1e-5 and np.abs(tv - ro["tvecs"]).max() < 1e-4
+
+
+def _check_against_oracle(r, ro):
+    assert r["iters"] == ro["iters"] and abs(r["rms"] - ro["rms"]) < 1e-8
+    assert np.abs(r["intr"][:4] - ro["intr"][:4]).max() / ro["intr"][1] < 1e-6 and np.abs(r["intr"][4:] - ro["intr"][4:]).max() < 1e-5
+    assert np.abs(r["rvecs"] - ro["rvecs"]).max() < 1e-5 and np.abs(r["tvecs"] - ro["tvecs"]).max() < 1e-4
+
+
+def test_c3_eight_shards_match_oracle():
+    """BASELINE.json configs[3] at its largest world size: the 1000-image x 9x6 set in EIGHT shards of 125 images
+    (ccal_calibrate_multi with the test box's one GPU listed eight times: the rank-ordered sum over eight rows, the
+    four-slot tag protocol and the 544-byte row at world = 8), against the ORACLE -- RMS to 1e-8 px, same
+    accepted-iteration count, parameters to the full-fit tolerances -- and against the one-GPU device fit."""
+    from cameracalibrations_amd.solver import calibrate_multi
+    wl, ro = _c3_oracle()
+    with _solver(wl, REF) as s:
+        _, base = s.calibrate()
+    for rep in range(2):
+        st, r = calibrate_multi(wl.obj, wl.img, wl.image_size, [0] * 8, aspect=wl.aspect, flags=wl.flags, max_iter=REF[0], eps=REF[1])
+        assert st == 0 and r["rejected"] == 0
+        _check_against_oracle(r, ro)
+        assert r["sweeps"] == base["sweeps"] and abs(r["rms"] - base["rms"]) < 1e-12
+        assert np.abs(r["intr"] - base["intr"]).max() < 1e-9 * base["intr"][1]
+        assert np.abs(r["rvecs"] - base["rvecs"]).max() < 1e-10 and np.abs(r["tvecs"] - base["tvecs"]).max() < 1e-9
+    from cameracalibrations_amd import _ffi
+    _ffi.lib().ccal_thread_cleanup()
+
+
+_C5_ORACLE = {}
+
+
+def _c5_oracle():
+    if not _C5_ORACLE:
+        wl = syn.named_workload("C5")
+        _C5_ORACLE.update(wl=wl, ro=_oracle(wl, REF, nthreads=8))
+    return _C5_ORACLE["wl"], _C5_ORACLE["ro"]
+
+
+def test_c5_single_gpu_matches_oracle_full_size():
+    """BASELINE.json configs[4]'s problem (10000 images x 15x10 corners, full k1..k3,p1,p2 model) whole on one GPU
+    against the ORACLE itself (its Schur mode fits the 1.5 M corners in seconds): RMS to 1e-8 px, same
+    accepted-iteration count, parameters to the full-fit tolerances."""
+    wl, ro = _c5_oracle()
+    with _solver(wl, REF) as s:
+        st, r = s.calibrate()
+    assert st in (0, 1)
+    _check_against_oracle(r, ro)
+
+
+def test_c5_eight_shards_match_oracle():
+    """BASELINE.json configs[4] as named: the 10000 x 15x10 problem in EIGHT shards of 1250 images (the per-GPU share
+    at 8 MI355X; here eight shards on the test box's one GPU driven by one host thread), against the ORACLE and
+    against the one-GPU device fit, plus the oracle's stationarity spot-check at the returned point."""
+    from cameracalibrations_amd.solver import calibrate_multi
+    wl, ro = _c5_oracle()
+    with _solver(wl, REF) as s:
+        _, base = s.calibrate()
+    st, r = calibrate_multi(wl.obj, wl.img, wl.image_size, [0] * 8, aspect=wl.aspect, flags=wl.flags, max_iter=REF[0], eps=REF[1])
+    assert st in (0, 1)
+    _check_against_oracle(r, ro)
+    assert r["iters"] == base["iters"] and r["sweeps"] == base["sweeps"] and abs(r["rms"] - base["rms"]) < 1e-11
+    assert np.abs(r["intr"] - base["intr"]).max() < 1e-8 * base["intr"][1]
+    assert np.abs(r["rvecs"] - base["rvecs"]).max() < 1e-9 and np.abs(r["tvecs"] - base["tvecs"]).max() < 1e-8
+    asp = wl.aspect if wl.flags & 2 else 0.0
+    for i in (0, 1249, 1250, 5000, 9999):           # first / last image of a shard, a shard boundary, the middle
+        G = orc.image_gram(wl.obj, wl.img[i], r["rvecs"][i], r["tvecs"][i], r["intr"], asp)
+        grad = G[:6, 15] / np.sqrt(np.diag(G)[:6] * G[15, 15])
+        assert np.abs(grad).max() < 5e-3            # (criteria (30, 1e-3): stopped at the reference's loose rule; oracle: 7e-4)
+    from cameracalibrations_amd import _ffi
+    _ffi.lib().ccal_thread_cleanup()
 
 
 def test_c3_single_gpu_matches_oracle_full_size():

@@ -1,5 +1,5 @@
-"""Copies what tools/r02_profiles.sh left under gpurun_out/ into profiles/ (tracked) and writes the per-instantiation
-kernel-trace summary.  usage: collect_profiles.py [round-prefix]   (default r02)"""
+"""Copies what tools/profiles.sh <round> left under gpurun_out/ into profiles/ (tracked) and writes the per-instantiation
+kernel-trace summary.  usage: collect_profiles.py [round-prefix]   (default r03)"""
 import csv
 import json
 import os
@@ -8,7 +8,7 @@ import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 
@@ -31,15 +31,19 @@ def trace_summary(path):
 
 runs = {"C3 1000x54 (bench.py --steps 50, as the driver runs it)": "c3", "C5 10000x150 on one GPU": "c5",
         "C5 per-GPU share at 8 GPUs (1250x150)": "c5shard"}
-summary = {"what": "rocprofv3 --kernel-trace of the commands in tools/r02_profiles.sh: duration of ccal::k_lm_trial by instantiation "
+summary = {"what": "rocprofv3 --kernel-trace of the commands in tools/profiles.sh: duration of ccal::k_lm_trial by instantiation "
                    "<exchange, looping, kind> (kind 0 = first launch of a solve, 1 = later trial, 2 = terminating prologue-only launch)",
            "runs": {k: trace_summary(os.path.join(G, R + "_prof", d, "prof_kernel_trace.csv")) for k, d in runs.items()}}
 json.dump(summary, open(os.path.join(P, R + "_kernel_trace_summary.json"), "w"), indent=1)
 for src, dst in (("_prof/c3/prof_kernel_stats.csv", "_bench_kernel_stats.csv"), ("_prof/c5/prof_kernel_stats.csv", "_c5_kernel_stats.csv"),
-                 ("_prof/c5shard/prof_kernel_stats.csv", "_c5_shard1250_kernel_stats.csv"), ("_prof/stamps.log", "_sweep_wave_stamps.txt")):
-    shutil.copy(os.path.join(G, R + src), os.path.join(P, R + dst))
-for src, dst in (("pmc/summary.json", "_pmc_traffic_summary.json"), ("pmc_util/summary.json", "_pmc_utilisation_summary.json"),
+                 ("_prof/c5shard/prof_kernel_stats.csv", "_c5_shard1250_kernel_stats.csv"), ("_prof/maps/prof_kernel_stats.csv", "_maps_kernel_stats.csv"),
+                 ("_prof/stamps.log", "_sweep_wave_stamps.txt")):
+    if os.path.exists(os.path.join(G, R + src)):
+        shutil.copy(os.path.join(G, R + src), os.path.join(P, R + dst))
+for src, dst in (("pmc/summary.json", "_pmc_traffic_summary.json"), ("pmc_c5/summary.json", "_c5_pmc_traffic_summary.json"),
+                 ("pmc_util/summary.json", "_pmc_utilisation_summary.json"),
                  ("pmc_util_c5/summary.json", "_c5_pmc_utilisation_summary.json"), ("wave_stamps_block7.json", "_wave_stamps.json")):
-    shutil.copy(os.path.join(G, src), os.path.join(P, R + dst))
+    if os.path.exists(os.path.join(G, src)):
+        shutil.copy(os.path.join(G, src), os.path.join(P, R + dst))
 for k, v in summary["runs"].items():
     print(k, {n.split("k_lm_trial")[1].split("(")[0]: round(d["mean_us"], 2) for n, d in v["by_kernel"].items()})
