@@ -202,9 +202,19 @@ CCAL_HD void rodrigues_RK(const double r[3], double R[9], double K[9]) {
     K[6] = b * xz - a * r[1];   K[7] = b * yz + a * r[0];   K[8] = sc + b * zz;
 }
 
-// point_rows with the rotation derivative in K form (same columns as point_rows).  `vm` = 1 for a real
-// corner, 0 for a padding lane: it rides on multiplications the rows make anyway (every Jacobian column carries a
-// factor fx or fy), so that a padding lane's two rows come out as exact zeros without 32 value selects.
+// point_rows with the rotation derivative in K form (same columns as point_rows), the six pose columns factored:
+// with d(x, y) the derivative of the normalised point, every pose column is
+//     (mu_j, mv_j) = diag(fx, fy) Jd (dx_j, dy_j),     (dx_j, dy_j) = z [1 0 -x; 0 1 -y] dX_j
+// where Jd = d(xd, yd)/d(x, y) = [Auu Auv; Auv Avv] is the SAME 2x2 distortion Jacobian for all six columns
+//     Auu = cd + 2 x^2 D + 2 p1 y + 6 p2 x     Auv = 2 x y D + 2 p1 x + 2 p2 y     Avv = cd + 2 y^2 D + 6 p1 y + 2 p2 x
+// (D = d cd / d r^2; collecting the terms of point_rows' per-column expressions).  So W = diag(fx, fy) Jd z [1 0 -x; 0 1 -y]
+// (2 x 3) is formed once per corner; the translation columns ARE its columns (dX_j = e_j), and a rotation column is
+//     W_r . (K[:,j] x (R M)) = K[:,j] . ((R M) x W_r)          (scalar triple product)
+// i.e. two cross products per corner and one 3-term dot per entry: 52 operations for the 12 pose entries instead of
+// 144 -- the rows are a third of a sweep's vector arithmetic where the chip is FP64-bound (10000 x 150).  Same
+// derivative, different rounding (a few ulp per entry); the residual column is evaluated exactly as before.
+// `vm` = 1 for a real corner, 0 for a padding lane: it rides on multiplications the rows make anyway (every Jacobian
+// column carries a factor fx or fy), so that a padding lane's two rows come out as exact zeros without 32 value selects.
 CCAL_HD void point_rows_K(const double M[3], double u_obs, double v_obs, const double R[9],
                           const double K[9], const double t[3], const double in[NINTR],
                           double aspect, double mu[NCOL], double mv[NCOL], double vm = 1.0) {
@@ -231,26 +241,29 @@ CCAL_HD void point_rows_K(const double M[3], double u_obs, double v_obs, const d
     else              { mu[6] = xdv; mu[7] = 0.0; }
     mv[6] = 0.0; mv[7] = yd * vm;
     mu[8] = vm; mu[9] = 0.0; mv[8] = 0.0; mv[9] = vm;
-    mu[10] = fxv * x * r2; mu[11] = fxv * x * r4; mu[12] = fxv * a1; mu[13] = fxv * a2; mu[14] = fxv * x * r6;
-    mv[10] = fyv * y * r2; mv[11] = fyv * y * r4; mv[12] = fyv * a3; mv[13] = fyv * a1; mv[14] = fyv * y * r6;
+    const double fxx = fxv * x, fyy = fyv * y;
+    mu[10] = fxx * r2; mu[11] = fxx * r4; mu[12] = fxv * a1; mu[13] = fxv * a2; mu[14] = fxx * r6;
+    mv[10] = fyy * r2; mv[11] = fyy * r4; mv[12] = fyv * a3; mv[13] = fyv * a1; mv[14] = fyy * r6;
 
+    // 2x2 distortion Jacobian (p-multiples are wave-uniform: hoisted out of the corner loop by the compiler)
+    const double D2 = dcd_dr2 + dcd_dr2, xD2 = x * D2, yD2 = y * D2;
+    const double p1_2 = 2.0 * p1, p2_2 = 2.0 * p2, p1_6 = 6.0 * p1, p2_6 = 6.0 * p2;
+    const double Auu = fma(p2_6, x, fma(p1_2, y, fma(x, xD2, cd)));
+    const double Auv = fma(p2_2, y, fma(p1_2, x, x * yD2));
+    const double Avv = fma(p2_2, x, fma(p1_6, y, fma(y, yD2, cd)));
+    // W = diag(fx, fy) Jd z [1 0 -x; 0 1 -y]: its columns are the translation columns
+    const double zx = z * fxv, zy = z * fyv;
+    const double w00 = zx * Auu, w01 = zx * Auv, w02 = -fma(w01, y, w00 * x);
+    const double w10 = zy * Auv, w11 = zy * Avv, w12 = -fma(w11, y, w10 * x);
+    mu[3] = w00; mu[4] = w01; mu[5] = w02;
+    mv[3] = w10; mv[4] = w11; mv[5] = w12;
+    // rotation columns: K[:,j] . ((R M) x W_r)
+    const double q0x = Yr * w02 - Zr * w01, q0y = Zr * w00 - Xr * w02, q0z = Xr * w01 - Yr * w00;
+    const double q1x = Yr * w12 - Zr * w11, q1y = Zr * w10 - Xr * w12, q1z = Xr * w11 - Yr * w10;
 #pragma unroll
-    for (int j = 0; j < 6; j++) {
-        double dX, dY, dZ;
-        if (j < 3) {   // K[:,j] x (R M)
-            const double kx = K[j], ky = K[3 + j], kz = K[6 + j];
-            dX = ky * Zr - kz * Yr;
-            dY = kz * Xr - kx * Zr;
-            dZ = kx * Yr - ky * Xr;
-        } else {
-            dX = (j == 3) ? 1.0 : 0.0; dY = (j == 4) ? 1.0 : 0.0; dZ = (j == 5) ? 1.0 : 0.0;
-        }
-        const double dx = z * (dX - x * dZ), dy = z * (dY - y * dZ);
-        const double dr2 = 2.0 * x * dx + 2.0 * y * dy;
-        const double dcd = dcd_dr2 * dr2;
-        const double da1 = 2.0 * (x * dy + y * dx);
-        mu[j] = fxv * (cd * dx + x * dcd + p1 * da1 + p2 * (dr2 + 4.0 * x * dx));
-        mv[j] = fyv * (cd * dy + y * dcd + p1 * (dr2 + 4.0 * y * dy) + p2 * da1);
+    for (int j = 0; j < 3; j++) {
+        mu[j] = K[j] * q0x + K[3 + j] * q0y + K[6 + j] * q0z;
+        mv[j] = K[j] * q1x + K[3 + j] * q1y + K[6 + j] * q1z;
     }
 }
 

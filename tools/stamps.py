@@ -23,7 +23,7 @@ from cameracalibrations_amd.solver import Solver  # noqa: E402
 
 L = F.lib()
 L.ccal_debug_stamps.restype = C.c_int
-wl = syn.named_workload("C3")
+wl = syn.named_workload(os.environ.get("CCAL_STAMP_WL", "C3"))
 names = ["entry", "state + accumulators + advance", "head -> pose (backsubst)", "rotation R,K", "point_rows",
          "tile store", "mfma gram", "Gram -> LDS", "chol6 + Y", "outputs + WG sum + atomics", "U + block store"]
 with Solver(0) as s:
