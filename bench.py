@@ -180,6 +180,30 @@ def maps_block(wl, rf, with_cpu=True, reps=20):
             ts.append(time.perf_counter() - t0)
         out["single_point_call_us"] = 1e6 * float(np.median(ts))
         out["single_point_call_us_mean"] = 1e6 * float(np.mean(ts))
+    # a caller that loops over points (the reference's own round-trip metric does, src/buildcalibrations.jl:53-58): 100
+    # point-wise calls one by one, the same loop through Calibration.batch() (queued, evaluated in one device call), and one
+    # call with the 100 points as an array
+    from cameracalibrations_amd.calibration import Calibration
+    cal = Calibration(f, c, rv, tv, 1.0, k, [])
+    p100 = [np.r_[rng.uniform(0, 8, 2), 0.0] for _ in range(100)]
+    arr100 = np.array(p100)
+
+    def med(fn, n=30):
+        fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return 1e6 * float(np.median(ts))
+
+    def buffered():
+        with cal.batch() as b:
+            for x in p100:
+                b(x, 1)
+    out["loop_of_100_points_us"] = med(buffered)
+    out["loop_of_100_points_unbuffered_us"] = med(lambda: [cal(x, 1) for x in p100], n=5)
+    out["one_call_100_points_us"] = med(lambda: cal(arr100, 1))
     if with_cpu:
         from oracle import oracle as orc
         n = min(N, 200)

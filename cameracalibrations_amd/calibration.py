@@ -75,6 +75,8 @@ class Calibration:
         """c(xyz, i) -> RowCol (real2image[i]); c(rowcol, i) -> XYZ (image2real[i]).
         Batched: (M,3) -> (M,2), (M,2) -> (M,3)."""
         i = self._index(extrinsic_index)
+        if isinstance(x, (list, tuple)) and len(x) and np.ndim(x[0]) == 1:
+            x = np.array(x, dtype=np.float64)              # a sequence of RowCol / XYZ points: one call for all of them
         x = np.asarray(x, dtype=np.float64)
         single = x.ndim == 1
         pts = np.atleast_2d(x)
@@ -86,6 +88,70 @@ class Calibration:
         else:
             raise TypeError("expected an XYZ (3-vector) or RowCol (2-vector)")
         return out[0] if single else out
+
+
+class _MapBatch:
+    """Buffer of point-wise map calls (Calibration.batch): `b(x, i)` queues one point and hands back the array its result
+    will be written to; leaving the `with` block (or `flush()`) evaluates everything queued in at most two device calls
+    (ccal_project_many / ccal_unproject_many with one point per pose entry).  A loop over points like the reference's
+    round-trip metric (src/buildcalibrations.jl:53-58) then costs two calls instead of two per point."""
+
+    def __init__(self, c):
+        self._c = c
+        self._q = {3: ([], [], []), 2: ([], [], [])}       # width of the input -> (points, pose indices, outputs)
+
+    def __call__(self, x, extrinsic_index=None):
+        i = self._c._index(extrinsic_index)
+        x = np.asarray(x, dtype=np.float64)
+        if x.shape not in ((3,), (2,)):
+            raise TypeError("expected an XYZ (3-vector) or RowCol (2-vector)")
+        pts, idx, outs = self._q[x.shape[0]]
+        out = np.full(5 - x.shape[0], np.nan)
+        pts.append(x)
+        idx.append(i)
+        outs.append(out)
+        return out
+
+    def flush(self):
+        c = self._c
+        s = _shared_solver(c.device)
+        for w, fn in ((3, s.project_many), (2, s.unproject_many)):
+            pts, idx, outs = self._q[w]
+            if not pts:
+                continue
+            x = np.array(pts, dtype=np.float64).reshape(len(pts), 1, w)
+            res = fn(x, c.f, c.c, c.k, c.rvecs[idx], c.tvecs[idx], c.checker_size)[:, 0, :]
+            for o, r in zip(outs, res):
+                o[:] = r
+            self._q[w] = ([], [], [])
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, *_):
+        if exc_type is None:
+            self.flush()
+
+
+def _batch(self):
+    """`with c.batch() as b: outs = [b(rc, i) for rc in pts]` -- point-wise calls, evaluated together (see _MapBatch)."""
+    return _MapBatch(self)
+
+
+def _map_all(self, x):
+    """Image n through pose n for all images in one call: x (N,M,3) -> (N,M,2) (real2image), (N,M,2) -> (N,M,3)
+    (image2real), or one (M,3) template through every pose (`c.(objpoints, i)` for all i, src/buildcalibrations.jl:29)."""
+    x = np.asarray(x, dtype=np.float64)
+    s = _shared_solver(self.device)
+    if x.shape[-1] == 3:
+        return s.project_many(x, self.f, self.c, self.k, self.rvecs, self.tvecs, self.checker_size)
+    if x.ndim == 3 and x.shape[-1] == 2:
+        return s.unproject_many(x, self.f, self.c, self.k, self.rvecs, self.tvecs, self.checker_size)
+    raise TypeError("expected (N,M,3) / (M,3) XYZ or (N,M,2) RowCol points")
+
+
+Calibration.batch = _batch
+Calibration.map_all = _map_all
 
 
 def rectification(c: Calibration, extrinsic_index=None) -> Callable:

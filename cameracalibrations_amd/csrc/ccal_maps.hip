@@ -18,41 +18,46 @@ namespace ccal {
 // The extrinsic part is one (rvec, tvec) per image: rt [6, N] in device (or device-visible pinned) memory.
 // Point streams are [3, M, N] / [2, M, N] (image index = blockIdx.y); xyz_stride = 0 maps ONE [3, M] template
 // through every image's pose (what calculate_errors and the plots do, src/buildcalibrations.jl:29).
+// (the image index strides over gridDim.y: a grid's y extent is capped at 65535, the image count is not)
 __global__ __launch_bounds__(256) void k_map_forward(const double *__restrict__ xyz, long long xyz_stride, double *__restrict__ rc,
-                                                      int M, const MapIntr in, const double *__restrict__ rt) {
-    const int i = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
+                                                      int M, int N, const MapIntr in, const double *__restrict__ rt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
-    const double *e = rt + (size_t)6 * img;
-    const double r[3] = {e[0], e[1], e[2]}, t[3] = {e[3], e[4], e[5]};
-    double R[9];
-    rodrigues_R(r, R);
-    const double *src = xyz + (size_t)img * xyz_stride;
-    const double p[3] = {src[3 * i], src[3 * i + 1], src[3 * i + 2]};
-    double o[2];
-    map_forward(p, in.f, in.c, in.k, R, t, 1.0 / in.cs, o);
-    double *dst = rc + (size_t)2 * M * img;
-    dst[2 * i] = o[0];
-    dst[2 * i + 1] = o[1];
+    for (int img = blockIdx.y; img < N; img += gridDim.y) {
+        const double *e = rt + (size_t)6 * img;
+        const double r[3] = {e[0], e[1], e[2]}, t[3] = {e[3], e[4], e[5]};
+        double R[9];
+        rodrigues_R(r, R);
+        const double *src = xyz + (size_t)img * xyz_stride;
+        const double p[3] = {src[3 * i], src[3 * i + 1], src[3 * i + 2]};
+        double o[2];
+        map_forward(p, in.f, in.c, in.k, R, t, 1.0 / in.cs, o);
+        double *dst = rc + (size_t)2 * M * img;
+        dst[2 * i] = o[0];
+        dst[2 * i + 1] = o[1];
+    }
 }
 
-__global__ __launch_bounds__(256) void k_map_inverse(const double *__restrict__ rc, double *__restrict__ xyz, int M, const MapIntr in,
-                                                      const double *__restrict__ rt) {
-    const int i = blockIdx.x * 256 + threadIdx.x, img = blockIdx.y;
+__global__ __launch_bounds__(256) void k_map_inverse(const double *__restrict__ rc, double *__restrict__ xyz, int M, int N,
+                                                      const MapIntr in, const double *__restrict__ rt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= M) return;
-    const double *e = rt + (size_t)6 * img;
-    const double r[3] = {e[0], e[1], e[2]}, t[3] = {e[3], e[4], e[5]};
-    double R[9], ti[3];
-    rodrigues_R(r, R);
+    for (int img = blockIdx.y; img < N; img += gridDim.y) {
+        const double *e = rt + (size_t)6 * img;
+        const double r[3] = {e[0], e[1], e[2]}, t[3] = {e[3], e[4], e[5]};
+        double R[9], ti[3];
+        rodrigues_R(r, R);
 #pragma unroll
-    for (int a = 0; a < 3; a++) ti[a] = -(R[a] * t[0] + R[3 + a] * t[1] + R[6 + a] * t[2]);
-    const double *src = rc + (size_t)2 * M * img;
-    const double q[2] = {src[2 * i], src[2 * i + 1]};
-    double o[3];
-    map_inverse(q, in.f, in.c, in.k, R, ti, in.cs, o);
-    double *dst = xyz + (size_t)3 * M * img;
-    dst[3 * i] = o[0];
-    dst[3 * i + 1] = o[1];
-    dst[3 * i + 2] = o[2];
+        for (int a = 0; a < 3; a++) ti[a] = -(R[a] * t[0] + R[3 + a] * t[1] + R[6 + a] * t[2]);
+        const double *src = rc + (size_t)2 * M * img;
+        const double q[2] = {src[2 * i], src[2 * i + 1]};
+        double o[3];
+        map_inverse(q, in.f, in.c, in.k, R, ti, in.cs, o);
+        double *dst = xyz + (size_t)3 * M * img;
+        dst[3 * i] = o[0];
+        dst[3 * i + 1] = o[1];
+        dst[3 * i + 2] = o[2];
+    }
 }
 
 // One workgroup per image: the four sums of calculate_errors for that image.
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256) void k_errors(const double *__restrict__ obj, 
 //  so that the four sequential sums are add-bound, not one memory round trip per image)
 __global__ __launch_bounds__(256) void k_errors_reduce(const double *__restrict__ partials, double *__restrict__ out,
                                                        int N) {
-    constexpr int CHUNK = 2048;                       // images per staging round (64 KB)
+    constexpr int CHUNK = 1024;                       // images per staging round (32 KB of static LDS)
     __shared__ double buf[4 * CHUNK];
     const int tid = threadIdx.x;
     double s = 0.0;
@@ -196,12 +201,12 @@ hipError_t launch_signal(hipStream_t stream, unsigned long long *flag, unsigned 
 
 hipError_t launch_map_forward(hipStream_t stream, const double *xyz, long long xyz_stride, double *rc, int M, int N,
                               const MapIntr &in, const double *rt) {
-    hipLaunchKernelGGL(k_map_forward, dim3((M + 255) / 256, N), dim3(256), 0, stream, xyz, xyz_stride, rc, M, in, rt);
+    hipLaunchKernelGGL(k_map_forward, dim3((M + 255) / 256, N < 65535 ? N : 65535), dim3(256), 0, stream, xyz, xyz_stride, rc, M, N, in, rt);
     return hipGetLastError();
 }
 hipError_t launch_map_inverse(hipStream_t stream, const double *rc, double *xyz, int M, int N, const MapIntr &in,
                               const double *rt) {
-    hipLaunchKernelGGL(k_map_inverse, dim3((M + 255) / 256, N), dim3(256), 0, stream, rc, xyz, M, in, rt);
+    hipLaunchKernelGGL(k_map_inverse, dim3((M + 255) / 256, N < 65535 ? N : 65535), dim3(256), 0, stream, rc, xyz, M, N, in, rt);
     return hipGetLastError();
 }
 hipError_t launch_errors(hipStream_t stream, const double *obj, const double *img, const MapIntr &in,

@@ -44,12 +44,12 @@ def rotation_vector(R):
     s = 0.5 * float(np.linalg.norm(w))
     c = 0.5 * (float(np.trace(R)) - 1.0)
     th = float(np.arctan2(s, c))
-    if th < 1e-8:
-        return 0.5 * w
-    if s > 1e-6:
-        return w * (th / (2.0 * s))
-    # th ~ pi: the skew part vanishes; the axis is the dominant column of R + I
-    B = 0.5 * (R + np.eye(3))
+    if c >= 0.0 or s > 1e-6:
+        # th <= pi / 2, or the skew part still carries the axis: w = 2 sin(th) n, so r = th n = w th / (2 s);
+        # th / (2 s) -> 1 / 2 as th -> 0 (no hole between a "small" and a "near pi" branch: near pi needs c < 0)
+        return w * (th / (2.0 * s)) if s > 1e-150 else 0.5 * w
+    # th ~ pi: the skew part vanishes; the symmetric part is c I + (1 - c) n n^T exactly, whatever is left of the skew part
+    B = (0.5 * (R + R.T) - c * np.eye(3)) / (1.0 - c)
     i = int(np.argmax(np.diag(B)))
     n = B[:, i] / np.sqrt(B[i, i])
     if w @ n < 0:
@@ -70,12 +70,22 @@ def _rvec_from_json(lin):
     raise ValueError(f"extrinsics[].linear: unsupported layout {a.shape}")
 
 
-def to_dict(c: Calibration):
+def to_dict(c: Calibration, rotation="matrix"):
+    """rotation = "matrix": extrinsics[].linear as the nested 3x3 (outer index = column) that StructTypes' ArrayType
+    gives an AbstractMatrix -- PROVISIONAL: read off the JSON3 / StructTypes rules, never checked against a file written by
+    the reference (it holds none); "vector": the three rotation-vector components, which `load` here
+    also accepts and a Julia-side `RotationVec(v...)` constructor call can take."""
+    if rotation not in ("matrix", "vector"):
+        raise ValueError("rotation must be 'matrix' or 'vector'")
     s = 1.0 / float(c.checker_size)
+
+    def lin(r):
+        if rotation == "vector":
+            return [float(v) for v in np.asarray(r, dtype=np.float64).reshape(3)]
+        return [[float(v) for v in col] for col in rotation_matrix(r).T]
     return {
         "intrinsic": {"linear": [float(c.f[0]), float(c.f[1])], "translation": [float(c.c[0]), float(c.c[1])]},
-        "extrinsics": [{"linear": [[float(v) for v in col] for col in rotation_matrix(r).T],
-                        "translation": [float(t[0]), float(t[1]), float(t[2])]}
+        "extrinsics": [{"linear": lin(r), "translation": [float(t[0]), float(t[1]), float(t[2])]}
                        for r, t in zip(c.rvecs, c.tvecs)],
         "scale": {"linear": [s, s, s]},
         "k": float(c.k),
@@ -99,10 +109,10 @@ def from_dict(d, device=0):
                        list(d["files"]), device)
 
 
-def save(file, c: Calibration):
-    """CameraCalibrations.save(file, c) (src/io.jl:28-32)."""
+def save(file, c: Calibration, rotation="matrix"):
+    """CameraCalibrations.save(file, c) (src/io.jl:28-32); `rotation`: see to_dict (the matrix form is provisional)."""
     with open(file, "w") as io:
-        json.dump(to_dict(c), io)
+        json.dump(to_dict(c, rotation), io)
 
 
 def load(file, device=0):

@@ -2,7 +2,10 @@
 #
 # UNTESTED IN THIS REPOSITORY: the build image has no Julia -- none of this file has ever been parsed or run.  The Python mirror
 # (cameracalibrations_amd/solver.py, tested on MI355X) makes exactly the same calls with the
-# same array layouts; keep the two in step.
+# same array layouts; keep the two in step.  What IS checked without Julia (tests/test_cabi.py): every `ccall` in this
+# file names a symbol of include/ccal.h and passes as many arguments, of the same C width, as cameracalibrations_amd/_ffi.py
+# declares for it.  Everything below `fit_model` -- `Context`, the map calls, `Calibration`, `fit`, `fit_corners` -- is
+# EXPERIMENTAL surface on top of the seam (INTEGRATION.md).
 #
 # Drop-in for the reference's FFI seam: define `fit_model` with the signature of
 # reference src/detect_fit.jl:27 and return the NamedTuple of :60.  In CameraCalibrations.jl
@@ -170,10 +173,23 @@ end
 (c::Calibration)(rc::RowCol, i::Int) = SVector{3}(unproject(c.ctx, reshape(Float64[rc...], 2, 1), c.f, c.c, c.k, c.rvecs[:, i], c.tvecs[:, i], c.checker_size))  # src/meta.jl:82
 (c::Calibration)(pts::Matrix{Float64}, i::Int) = size(pts, 1) == 3 ? project(c.ctx, pts, c.f, c.c, c.k, c.rvecs[:, i], c.tvecs[:, i], c.checker_size) :
                                                                     unproject(c.ctx, pts, c.f, c.c, c.k, c.rvecs[:, i], c.tvecs[:, i], c.checker_size)
-(c::Calibration)(x) = c(x, findfirst(contains(r"extrinsic"), c.files))      # src/meta.jl:90-93
+# a vector of points maps in ONE device call (a loop over points like src/buildcalibrations.jl:53-58 should be written
+# `c(pts, i)` or `c.(Ref(pts), i)`: a point-wise call costs a launch and a completion wait, ~20 us)
+(c::Calibration)(pts::AbstractVector{<:XYZ}, i::Int) = [SVector{2}(col) for col in eachcol(c(Float64[p[d] for d in 1:3, p in pts], i))]
+(c::Calibration)(pts::AbstractVector{<:RowCol}, i::Int) = [SVector{3}(col) for col in eachcol(c(Float64[p[d] for d in 1:2, p in pts], i))]
+# all images at once, image n through pose n: [3,M,N] or one [3,M] template -> [2,M,N]; [2,M,N] -> [3,M,N]
+map_all(c::Calibration, x::Array{Float64}) = size(x, 1) == 3 ? project_many(c.ctx, x, c.f, c.c, c.k, c.rvecs, c.tvecs, c.checker_size) :
+                                                               unproject_many(c.ctx, x, c.f, c.c, c.k, c.rvecs, c.tvecs, c.checker_size)
+
+function extrinsic_index(c::Calibration)                                    # src/meta.jl:90-93
+    i = findfirst(contains(r"extrinsic"), c.files)
+    i === nothing && throw(ArgumentError("no file name matches r\"extrinsic\""))   # (the reference fails on its `nothing` index)
+    return i
+end
+(c::Calibration)(x) = c(x, extrinsic_index(c))
 
 rectification(c::Calibration, i) = rc -> c(rc, i)[SVector(1, 2)]            # src/meta.jl:99-103
-rectification(c::Calibration) = rectification(c, findfirst(contains(r"extrinsic"), c.files))
+rectification(c::Calibration) = rectification(c, extrinsic_index(c))
 
 """
     fit_corners(imgpointss, n_corners, checker_size, sz; files, aspect, with_distortion, inverse_samples, device)
@@ -181,14 +197,14 @@ rectification(c::Calibration) = rectification(c, findfirst(contains(r"extrinsic"
 `_detect_corners` in src/detect_fit.jl:63-72 and src/buildcalibrations.jl:12-26.  Returns `(c, ϵ)`.
 """
 function fit_corners(imgpointss, n_corners, checker_size, sz; files = ["$i.png" for i in 1:length(imgpointss)], aspect = 1,
-                     with_distortion = true, inverse_samples = 100, device = 0)
+                     with_distortion = true, inverse_samples = 100, device = 0, ctx = Context(device))
     @assert !isempty(imgpointss) "No checkers were detected in any of the images, perhaps try a different `n_corners`."   # src/detect_fit.jl:66
     n1, n2 = n_corners
     objpoints = [SVector{3, Float64}(i - 1, j - 1, 0) for i in 1:n1, j in 1:n2, _ in 1:1]          # src/detect_fit.jl:69
     m = fit_model(sz, objpoints, imgpointss, n_corners, with_distortion, aspect; device)
     N, P = length(imgpointss), n1 * n2
     c = Calibration(SVector(m.frow, m.fcol), SVector(m.crow, m.ccol), reduce(hcat, m.Rs), reduce(hcat, m.ts), Float64(checker_size),
-                    m.k, collect(String, files), Context(device))
+                    m.k, collect(String, files), ctx)
     obj = Float64[(p - 1) % n1 * (d == 1) + (p - 1) ÷ n1 * (d == 2) for d in 1:3, p in 1:P] .* checker_size   # src/buildcalibrations.jl:15
     img = Array{Float64}(undef, 2, P, N)
     for (i, mm) in enumerate(imgpointss), (p, rc) in enumerate(vec(mm))
@@ -200,9 +216,11 @@ function fit_corners(imgpointss, n_corners, checker_size, sz; files = ["$i.png" 
 end
 
 """
-    fit(files, n_corners, checker_size; aspect, with_distortion, inverse_samples, detector)
-src/buildcalibrations.jl:12-26 with corner detection on the device (`detector(file) -> (gray::Matrix{UInt8})` loads an
-image; images without a full board are skipped like the reference's `missing`, src/detect_fit.jl:65).
+    fit(files, n_corners, checker_size; aspect, with_distortion, inverse_samples, load_gray)
+src/buildcalibrations.jl:12-26 with corner detection on the device.  `load_gray(file) -> Matrix{UInt8}` loads an image (the
+reference's `fit` has no such keyword: it reads the files itself through FileIO / OpenCV.jl, which this binding does not
+depend on); images without a full board are skipped like the reference's `missing`, src/detect_fit.jl:65.  One device
+context serves the detection, the fit's error metrics and the returned `Calibration`.
 """
 function fit(files, n_corners, checker_size; aspect = 1, with_distortion = true, inverse_samples = 100, device = 0, load_gray)
     ctx = Context(device)
@@ -214,7 +232,7 @@ function fit(files, n_corners, checker_size; aspect = 1, with_distortion = true,
         corners = detect_corners(ctx, gray, n_corners)
         ismissing(corners) || push!(found, (file, [SVector(rc...) for rc in corners]))
     end
-    return fit_corners(last.(found), n_corners, checker_size, sz; files = first.(found), aspect, with_distortion, inverse_samples, device)
+    return fit_corners(last.(found), n_corners, checker_size, sz; files = first.(found), aspect, with_distortion, inverse_samples, device, ctx)
 end
 
 end # module

@@ -118,3 +118,84 @@ def test_argument_checks_need_no_device(lib):
         with pytest.raises(F.CcalError) as e:
             calibrate_multi(obj, img, (1500, 2000), [0, 1])
         assert e.value.code == F.E_DEVICE or e.value.code == -6
+
+
+def _julia_ccalls(text):
+    """(symbol, return type, [argument types]) of every `ccall((:sym, LIB), Ret, (types...), args...)` in a Julia source"""
+    out, pos = [], 0
+    while True:
+        k = text.find("ccall((:", pos)
+        if k < 0:
+            return out
+        depth, j = 0, k + len("ccall")
+        while True:                                    # the balanced extent of ccall( ... )
+            depth += text[j] == "("
+            depth -= text[j] == ")"
+            j += 1
+            if depth == 0:
+                break
+        body = text[k + len("ccall("):j - 1]
+        sym = body[body.index(":") + 1:body.index(",")].strip()
+        rest = body[body.index(")") + 1:].lstrip(", \n")         # after (:sym, LIB)
+        ret, rest = rest.split(",", 1)
+        rest = rest.lstrip()
+        assert rest[0] == "(", (sym, rest[:40])
+        depth, e = 0, 0
+        while True:
+            depth += rest[e] == "("
+            depth -= rest[e] == ")"
+            e += 1
+            if depth == 0:
+                break
+        types = [t.strip() for t in rest[1:e - 1].replace("\n", " ").split(",") if t.strip()]
+        args, d, cur = [], 0, ""
+        for ch in rest[e:].lstrip(", \n"):              # top-level commas of the argument list
+            d += ch in "([{"
+            d -= ch in ")]}"
+            if ch == "," and d == 0:
+                args.append(cur.strip())
+                cur = ""
+            else:
+                cur += ch
+        if cur.strip():
+            args.append(cur.strip())
+        out.append((sym, ret.strip(), types, args))
+        pos = j
+
+
+def test_julia_binding_matches_the_c_abi():
+    """julia/CameraCalibrationsAMD.jl cannot be run here (no Julia in the image); what can be checked is that every `ccall`
+    names a symbol of the C ABI and declares -- and passes -- exactly the arguments cameracalibrations_amd/_ffi.py declares
+    for it, with the same C widths (pointer / Int32 / UInt32 / Int64 / Float64)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "julia", "CameraCalibrationsAMD.jl")).read()
+    calls = _julia_ccalls(text)
+    assert len(calls) >= 10
+
+    def kind_jl(t):
+        if t.startswith(("Ptr{", "Ref{")) or t in ("Cstring",):
+            return "ptr"
+        return {"Int32": "i32", "UInt32": "u32", "Int64": "i64", "Float64": "f64", "Cvoid": "void"}[t]
+
+    def kind_c(t):
+        if t is None:
+            return "void"
+        if t in (C.c_int, C.c_int32):
+            return "i32"
+        if t is C.c_uint32:
+            return "u32"
+        if t is C.c_int64:
+            return "i64"
+        if t is C.c_double:
+            return "f64"
+        return "ptr"                                   # c_void_p, c_char_p, POINTER(...), callbacks
+    seen = set()
+    for sym, ret, types, args in calls:
+        assert sym in F.SIGNATURES, sym
+        res, argtypes = F.SIGNATURES[sym]
+        assert kind_jl(ret) == kind_c(res), (sym, ret)
+        assert [kind_jl(t) for t in types] == [kind_c(t) for t in argtypes], (sym, types)
+        assert len(args) == len(types), (sym, len(args), len(types))
+        seen.add(sym)
+    assert {"ccal_calibrate", "ccal_calibrate_multi", "ccal_project", "ccal_unproject", "ccal_errors", "ccal_detect_corners",
+            "ccal_project_many", "ccal_unproject_many", "ccal_create", "ccal_destroy", "ccal_last_error"} <= seen

@@ -880,6 +880,37 @@ def test_many_image_maps_match_per_image_calls_and_oracle():
         assert np.abs(back - xyz[None]).max() < 1e-8          # round trip on the board plane
 
 
+def test_point_wise_calls_through_a_batch():
+    """Calibration.batch(): a loop of point-wise calls like the reference's round-trip metric (src/buildcalibrations.jl:53-58)
+    is evaluated in two device calls; results equal the per-point calls bit for bit and the oracle's maps; sequences of
+    points and Calibration.map_all (image n through pose n) likewise."""
+    from cameracalibrations_amd.calibration import Calibration
+    rng = np.random.default_rng(9)
+    N = 6
+    rv = rng.uniform(-0.4, 0.4, (N, 3))
+    tv = np.c_[rng.uniform(-2, 2, (N, 2)), rng.uniform(9, 15, N)]
+    c = Calibration(np.array([1600.0, 1610.0]), np.array([750.0, 1000.0]), rv, tv, 2.5, -0.11, [f"{i}.png" for i in range(N)])
+    pts = [(np.r_[rng.uniform(0, 8, 2), 0.0], int(rng.integers(1, N + 1))) for _ in range(100)]
+    with c.batch() as b:
+        fwd = [b(x, i) for x, i in pts]
+        assert np.isnan(fwd[0]).all()                          # nothing is evaluated before the block ends
+    with c.batch() as b:
+        back = [b(rc, i) for rc, (_, i) in zip(fwd, pts)]
+    for (x, i), rc, xyz in zip(pts[:12], fwd, back):
+        assert np.array_equal(rc, c(x, i)) and np.array_equal(xyz, c(rc, i))
+        assert np.abs(rc - orc.map_forward(x[None], c.f, c.c, c.k, rv[i - 1], tv[i - 1], 2.5)[0]).max() < 1e-9
+    assert max(np.abs(xyz - x).max() for (x, _), xyz in zip(pts, back)) < 1e-8      # round trip on the board plane
+    seq = c([x for x, _ in pts[:7]], 2)                        # a sequence of points: one call
+    assert seq.shape == (7, 2) and np.array_equal(seq[3], c(pts[3][0], 2))
+    tmpl = np.c_[rng.uniform(0, 8, (9, 2)), np.zeros(9)]
+    allp = c.map_all(tmpl)
+    assert allp.shape == (N, 9, 2) and np.array_equal(allp[4], c(tmpl, 5))
+    assert np.abs(c.map_all(allp) - tmpl[None]).max() < 1e-8
+    with pytest.raises(TypeError):
+        with c.batch() as b:
+            b(np.zeros(4), 1)
+
+
 def test_cached_contexts_are_released_at_thread_exit():
     """ccal_calibrate keeps one context per host thread (stream, ~25 device buffers, launch graph); a thread that ends
     must give them back (thread_local guard in csrc/ccal_api.hip), or a pool of short-lived worker threads leaks."""

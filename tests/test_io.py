@@ -103,6 +103,33 @@ def test_rotation_vector_inverse():
         cio.rotation_vector(np.diag([1.0, 1.0, -1.0]))
 
 
+def test_rotation_vector_round_trip_over_every_angle():
+    """theta from 1e-12 to pi with random axes: no hole between the small-angle and the near-pi branch (rotation vectors of
+    5e-7 rad used to come back as their dominant axis component only)."""
+    rng = np.random.default_rng(11)
+    for th in np.r_[np.logspace(-12, 0, 97), np.linspace(1.0, np.pi, 60), np.pi - np.logspace(-12, -1, 45)]:
+        for _ in range(4):
+            n = rng.normal(size=3)
+            r = n / np.linalg.norm(n) * th
+            back = cio.rotation_vector(cio.rotation_matrix(r))
+            if np.pi - th < 1e-6:        # at pi the axis sign is free: compare the rotations
+                assert np.abs(cio.rotation_matrix(back) - cio.rotation_matrix(r)).max() < 1e-9, th
+            else:
+                assert np.abs(back - r).max() < 1e-9 * max(th, 1e-3) + 1e-16, (th, back, r)
+
+
+def test_save_rotation_forms(tmp_path):
+    rng = np.random.default_rng(3)
+    c = cc.Calibration(rng.random(2), rng.random(2), rng.random((5, 3)), rng.random((5, 3)), 2.5, 0.1, list("abcde"))
+    for form, shape in (("matrix", (3, 3)), ("vector", (3,))):
+        f = tmp_path / f"c_{form}.json"
+        cc.save(str(f), c, rotation=form)
+        assert np.asarray(json.loads(f.read_text())["extrinsics"][0]["linear"]).shape == shape
+        assert np.abs(cc.load(str(f)).rvecs - c.rvecs).max() < 1e-14
+    with pytest.raises(ValueError):
+        cio.to_dict(c, rotation="quaternion")
+
+
 def test_round_trip(tmp_path):
     rng = np.random.default_rng(0)
     for _ in range(100):                 # test/runtests.jl:88-98: 100 random CalibrationIO round trips
