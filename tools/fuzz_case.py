@@ -1,0 +1,74 @@
+"""One case of tools/fuzz_parity.py replayed with both trajectories side by side: which decision differs between the
+device and the oracle, and by how much the two errors it compared differ.   fuzz_case.py --seed 51 --case 242"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cameracalibrations_amd import synthetic as syn  # noqa: E402
+from cameracalibrations_amd.solver import Solver  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seed", type=int, required=True)
+ap.add_argument("--case", type=int, required=True)
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
+FLAG_BITS = [syn.FIX_ASPECT_RATIO, syn.FIX_PRINCIPAL_POINT, syn.ZERO_TANGENT_DIST, syn.FIX_K1, syn.FIX_K2, syn.FIX_K3,
+             syn.FIX_TANGENT_DIST]
+for case in range(args.case + 1):            # the generator of fuzz_parity.py, draw for draw
+    n1, n2 = int(rng.integers(3, 17)), int(rng.integers(3, 13))
+    if n1 * n2 > 192 or n1 * n2 < 6:
+        continue
+    N = int(rng.choice([1, 2, 3, 4, 5, 7, 12, 20, 33, 64, 130, 257]))
+    model = str(rng.choice(["ref", "pinhole", "k1k2p1p2", "full"]))
+    flags = 0
+    for b in FLAG_BITS:
+        if rng.random() < 0.35:
+            flags |= int(b)
+    sigma = float(rng.choice([0.0, 0.05, 0.3]))
+    aspect = float(rng.choice([1.0, 0.8, 1.3])) if (flags & syn.FIX_ASPECT_RATIO) else 1.0
+    depth = (14.0, 28.0) if max(n1, n2) > 11 else (8.0, 16.0)
+    eps = float(rng.choice([1e-3, 1e-6]))
+    wl_seed = int(rng.integers(1, 1 << 30))
+    if case < args.case:
+        continue
+    wl = syn.make_workload("fuzz", (n1, n2), N, "ref" if (flags & syn.FIX_ASPECT_RATIO) else model, seed=wl_seed, sigma=sigma,
+                           depth=depth, aspect=aspect)
+print(f"case {args.case} of seed {args.seed}: {n1}x{n2} N={N} model={model} flags=0x{flags:x} sigma={sigma} aspect={aspect} eps={eps}")
+ro = orc.calibrate(wl.obj, wl.img, wl.image_size, aspect=aspect, flags=flags, max_iter=30, eps=eps, solver="schur")
+with Solver(0) as s:
+    s.set_problem(wl.obj, wl.n_images, wl.image_size, aspect=aspect, flags=flags, max_iter=30, eps=eps)
+    s.set_image_points(wl.img)
+    st, r = s.calibrate()
+    tr = [t for t in s.trace() if t["accepted"] != 2]
+    i0, rt0 = s.get_init()
+print(f"device: iters {r['iters']} rms {r['rms']!r}   oracle: iters {ro['iters']} rms {ro['rms']!r}")
+print("initial intrinsics |device - oracle|:", float(np.abs(i0 - ro["init_intr"]).max()))
+to = ro["trace"]
+print("trial  device(accepted, lg10 lambda, err)                 oracle(accepted, lg10 lambda, err)              rel. err difference")
+prev_d = prev_o = None
+for k in range(max(len(tr), len(to))):
+    d = tr[k] if k < len(tr) else None
+    o = to[k] if k < len(to) else None
+    fd = f"{d['accepted']} {d['lambda_lg10']:3d} {d['err']!r:24}" if d else " " * 30
+    fo = f"{o['accepted']} {o['lambda_lg10']:3d} {o['err']!r:24}" if o else " " * 30
+    rel = abs(d["err"] - o["err"]) / abs(o["err"]) if (d and o) else float("nan")
+    mark = ""
+    if d and o and (d["accepted"], d["lambda_lg10"]) != (o["accepted"], o["lambda_lg10"]):
+        mark = "  <-- first different decision" if not getattr(sys.modules[__name__], "_marked", False) else ""
+        if mark:
+            _marked = True
+            if prev_d is not None:
+                print(f"       (the error each side compared against: device {prev_d!r}, oracle {prev_o!r};"
+                      f" margins: device {d['err'] - prev_d:+.3e}, oracle {o['err'] - prev_o:+.3e})")
+    print(f"{k:4d}   {fd}   {fo}   {rel:.2e}{mark}")
+    if d and d["accepted"] == 1:
+        prev_d = d["err"]
+    if o and o["accepted"] == 1:
+        prev_o = o["err"]
+    if k == 0 and d and o:
+        prev_d, prev_o = (prev_d or d["err"]), (prev_o or o["err"])
