@@ -81,6 +81,7 @@ SIGNATURES = {
     "ccal_init_extrinsics": (C.c_int, [C.c_void_p]),
     "ccal_set_extrinsics": (C.c_int, [C.c_void_p, _dp]),
     "ccal_lm_run": (C.c_int, [C.c_void_p]),
+    "ccal_fit": (C.c_int, [C.c_void_p]),
     "ccal_set_sweep_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "ccal_set_graph": (C.c_int, [C.c_void_p, C.c_int32]),
     "ccal_get_result": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.POINTER(Stats)]),

@@ -539,10 +539,14 @@ static int finish_init_check(ccal_ctx *c, bool intr, bool extr) {
     return CCAL_OK;
 }
 
+static int signal_and_spin(ccal_ctx *c);
+
+// (the wait is a spin on a completion word in pinned memory: a blocking stream synchronisation costs tens of
+//  microseconds of wake-up latency, comparable to the initialisation kernels themselves)
 static int finish_init(ccal_ctx *c, bool intr, bool extr) {
     int rc = finish_init_enqueue(c);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if ((rc = signal_and_spin(c)) != CCAL_OK) return rc;
     return finish_init_check(c, intr, extr);
 }
 
@@ -1046,6 +1050,36 @@ int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int
     } while (0);
     c->defer_sync = false;
     if (rc < 0) {                  // leave no half-finished work behind on the cached stream
+        const std::string keep = g_err;
+        (void)hipStreamSynchronize(c->stream);
+        g_err = keep;
+    }
+    return rc;
+}
+
+// Initialisation + LM on the problem and image points already set on this context (host copy or device pointer), as
+// one pipeline: every stage is enqueued behind the previous one, the host waits once (the LM's progress word); the
+// initialisation's flags and values are read back in front of the LM's launches, so they have landed by then.
+int ccal_fit(ccal_ctx *c) {
+    if (!c) return fail(CCAL_E_ARG, "ccal_fit: ctx == NULL");
+    if (!c->have_problem || !c->have_img) return fail(CCAL_E_STATE, "ccal_fit: problem / image points not set");
+    const bool guess = (c->flags & CCAL_USE_INTRINSIC_GUESS) != 0;
+    if (guess && !c->have_intr) return fail(CCAL_E_STATE, "ccal_fit: USE_INTRINSIC_GUESS without ccal_set_intrinsics");
+    int rc = CCAL_OK, lm_rc = CCAL_OK;
+    c->defer_sync = true;
+    do {
+        if (!guess && (rc = ccal_init_intrinsics(c)) < 0) break;
+        if ((rc = ccal_init_extrinsics(c)) < 0) break;
+        if ((rc = finish_init_enqueue(c)) < 0) break;
+        lm_rc = ccal_lm_run(c);
+        const std::string lm_err = g_err;
+        if (lm_rc < 0) (void)hipStreamSynchronize(c->stream);     // (the LM did not wait for its own completion)
+        // initialisation failures explain (and outrank) whatever the LM reported on garbage
+        if ((rc = finish_init_check(c, !guess, true)) < 0) break;
+        if ((rc = lm_rc) < 0) g_err = lm_err;
+    } while (0);
+    c->defer_sync = false;
+    if (rc < 0) {
         const std::string keep = g_err;
         (void)hipStreamSynchronize(c->stream);
         g_err = keep;

@@ -146,6 +146,10 @@ class Solver:
     def lm_run(self):
         return F.check(F.lib().ccal_lm_run(self._h))
 
+    def fit(self):
+        """initialisation + LM as one pipeline with a single wait (ccal_fit); returns the LM's status"""
+        return F.check(F.lib().ccal_fit(self._h))
+
     def result(self):
         intr, ip = F.out64(F.NINTR)
         rv, rvp = F.out64(self.N, 3)

@@ -168,6 +168,10 @@ int  ccal_lm_run(ccal_ctx *ctx);
 /* A solve is replayed as one hipGraph (default; CCAL_NO_GRAPH=1 in the environment turns that off at ccal_create) or
  * launched kernel by kernel: same kernels, same results, different host cost. */
 int  ccal_set_graph(ccal_ctx *ctx, int32_t enable);
+/* A4 + A5 + A6-A9 as ONE pipeline on the problem and image points already set (e.g. a device pointer): the stages are
+ * enqueued back to back and the host waits once.  Same results as the three calls above; their per-stage times in
+ * ccal_stats then only cover the enqueueing. */
+int  ccal_fit(ccal_ctx *ctx);
 /* Bracket every sweep launch of the next ccal_lm_run calls with a HIP event pair on the launch
  * stream and report the mean in ccal_stats.sweep_us (roofline figure of bench.py). */
 int  ccal_set_sweep_timing(ccal_ctx *ctx, int32_t enable);

@@ -880,6 +880,39 @@ def test_many_image_maps_match_per_image_calls_and_oracle():
         assert np.abs(back - xyz[None]).max() < 1e-8          # round trip on the board plane
 
 
+def test_one_pipeline_fit_equals_the_stages():
+    """ccal_fit (initialisation + LM enqueued back to back, one wait) == the three stage calls, bit for bit, also when
+    repeated and on a device-resident corner array; a failed initialisation still surfaces as its own error."""
+    import torch
+
+    from cameracalibrations_amd import _ffi as F
+    for name, n in (("C2", 37), ("REF", 9), ("C5", 7)):
+        wl = syn.named_workload(name, n_images=n)
+        with _solver(wl, REF) as s:
+            st, a = s.calibrate()
+            for _ in range(2):
+                assert s.fit() == st
+                b = s.result()
+                for k in ("intr", "rvecs", "tvecs"):
+                    assert np.array_equal(a[k], b[k]), (name, k)
+                assert a["rms"] == b["rms"] and a["iters"] == b["iters"] and a["sweeps"] == b["sweeps"]
+        with Solver(0) as s:
+            s.set_problem(wl.obj, wl.n_images, wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=REF[0], eps=REF[1])
+            s.set_image_points(torch.from_numpy(wl.img).cuda())
+            assert s.fit() == st and np.array_equal(s.result()["intr"], a["intr"])
+    wl = syn.named_workload("C2", n_images=5)
+    bad = wl.img.copy()
+    bad[2] = bad[2, 0]                                         # one image with all corners in one spot: no homography
+    with Solver(0) as s:
+        s.set_problem(wl.obj, 5, wl.image_size, aspect=wl.aspect, flags=wl.flags)
+        s.set_image_points(bad)
+        with pytest.raises(F.CcalError) as e:
+            s.fit()
+        assert e.value.code in (F.E_DEGENERATE, F.E_NONFINITE)
+        s.set_image_points(wl.img)                             # the context is usable afterwards
+        assert s.fit() in (0, 1) and 0.05 < s.result()["rms"] < 0.3
+
+
 def test_point_wise_calls_through_a_batch():
     """Calibration.batch(): a loop of point-wise calls like the reference's round-trip metric (src/buildcalibrations.jl:53-58)
     is evaluated in two device calls; results equal the per-point calls bit for bit and the oracle's maps; sequences of
