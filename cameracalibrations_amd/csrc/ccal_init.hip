@@ -7,10 +7,12 @@
 //   A5  cvFindExtrinsicCameraParams2, planar branch: homography on normalised points,
 //       decomposition, orthonormalisation, 6-parameter LM polish
 //
-// Mapping: ONE 64-lane workgroup (= one wavefront) per image, one lane per corner; sums over
-// corners go through the LDS-staged f64 MFMA Gram of ccal_wave.hpp or wave butterflies; the
-// small dense algebra (9x9 inverse iteration, 8x8 / 6x6 Cholesky, 3x3 polar) is wave-uniform
-// register arithmetic.  Per-image iteration counts differ, hence one wave per workgroup.
+// Mapping: ONE 64-lane workgroup (= one wavefront) per image, one lane per corner; the normal equations of these
+// small problems (24-30 distinct sums over the corners) are formed per lane and summed over the lanes by a
+// transpose-reduce through LDS (wave_sums_lds, ccal_wave.hpp: a 16-wide MFMA Gram computes 256 entries to deliver
+// them, which cost a tile store, 14 matrix instructions and a read-back per pass), single sums by wave butterflies;
+// the small dense algebra (9x9 inverse iteration, 8x8 / 6x6 Cholesky, 3x3 polar) is wave-uniform register
+// arithmetic.  Per-image iteration counts differ, hence one wave per workgroup.
 #include <hip/hip_runtime.h>
 
 #include "ccal_kernels.hpp"
@@ -153,54 +155,60 @@ __device__ double homog_error(const Pts &pts, int P, int lane, const double h[8]
     return wave_sum(s);
 }
 
-// A (8x8 packed lower) = J^T J, v = J^T r, S = r^T r at h.  The u-row of a correspondence touches
-// only parameters {0,1,2,6,7} and the v-row only {3,4,5,6,7}, so both fit the packed 8-column Gram
-// (ccal_wave.hpp): u-row -> [J0 J1 J2 J6 J7 eu 0 0], v-row -> [J3 J4 J5 J6 J7 ev 0 0].
+// A (8x8 packed lower) = J^T J, v = J^T r, S = r^T r at h.  The u-row of a correspondence touches only parameters
+// {0,1,2,6,7} and the v-row only {3,4,5,6,7}, and both carry the same first three entries (Mx w, My w, w): of the 45
+// entries 30 are distinct non-zero sums -- formed per lane, accumulated over the passes and summed over the lanes once
+// (wave_sums_lds), instead of a 16-wide MFMA Gram per pass that computes 256 entries to deliver them.
+constexpr int HSUMS = 30;
 template <class Pts>
-__device__ void homog_normal_eq(const Pts &pts, int P, int lane, const double h[8], double *tile, double *Gs,
+__device__ void homog_normal_eq(const Pts &pts, int P, int lane, const double h[8], double *scratch,
                                 double A[36], double v[8], double &S) {
-    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    double acc[HSUMS];
+#pragma unroll
+    for (int k = 0; k < HSUMS; k++) acc[k] = 0.0;
     for (int c0 = 0; c0 < P; c0 += 64) {
-        const int p = c0 + lane;
-        const bool valid = p < P;
+        const int pi = c0 + lane;
+        const bool valid = pi < P;
         double Mx, My, mx, my, eu, ev, ww, xi, yi;
-        pts.get(valid ? p : P - 1, Mx, My, mx, my);
+        pts.get(valid ? pi : P - 1, Mx, My, mx, my);
         homog_point(h, Mx, My, mx, my, eu, ev, ww, xi, yi);
-        const double ru[8] = {Mx * ww, My * ww, ww, -Mx * ww * xi, -My * ww * xi, eu, 0.0, 0.0};
-        const double rv[8] = {Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi, ev, 0.0, 0.0};
-        tile8_store_rows(tile, lane, ru, rv, valid);
-        wave_lds_sync();      // (one wave per workgroup)
-        tile8_gram(tile, lane, min(64, P - c0), acc0, acc1);
-        wave_lds_sync();      // (one wave per workgroup)
+        const double vm = valid ? 1.0 : 0.0;                  // padding lanes: zero rows
+        const double w = ww * vm, p = Mx * w, q = My * w;
+        eu *= vm; ev *= vm;
+        const double ux = -p * xi, uy = -q * xi, vx = -p * yi, vy = -q * yi;
+        acc[0] += p * p; acc[1] += p * q; acc[2] += q * q; acc[3] += p * w; acc[4] += q * w; acc[5] += w * w;
+        acc[6] += ux * p; acc[7] += ux * q; acc[8] += ux * w; acc[9] += uy * p; acc[10] += uy * q; acc[11] += uy * w;
+        acc[12] += vx * p; acc[13] += vx * q; acc[14] += vx * w; acc[15] += vy * p; acc[16] += vy * q; acc[17] += vy * w;
+        acc[18] += ux * ux + vx * vx; acc[19] += ux * uy + vx * vy; acc[20] += uy * uy + vy * vy;
+        acc[21] += p * eu; acc[22] += q * eu; acc[23] += w * eu; acc[24] += p * ev; acc[25] += q * ev; acc[26] += w * ev;
+        acc[27] += ux * eu + vx * ev; acc[28] += uy * eu + vy * ev;
+        acc[29] += eu * eu + ev * ev;
     }
-    gram_to_lds(Gs, lane, acc0, acc1);
-    wave_lds_sync();      // (one wave per workgroup)
-    // packed index k of parameter a inside the u-block (0-2, 6->3, 7->4) and the v-block (3-5 -> 0-2, 6->3, 7->4)
+    double t[HSUMS];
+    wave_sums_lds<HSUMS>(acc, scratch, lane, t);
+    // (0..2)^2 and (3..5)^2 blocks are the same sums; (3..5) x (0..2) is structurally zero
+    A[tri(0, 0)] = t[0]; A[tri(1, 0)] = t[1]; A[tri(1, 1)] = t[2]; A[tri(2, 0)] = t[3]; A[tri(2, 1)] = t[4]; A[tri(2, 2)] = t[5];
+    A[tri(3, 3)] = t[0]; A[tri(4, 3)] = t[1]; A[tri(4, 4)] = t[2]; A[tri(5, 3)] = t[3]; A[tri(5, 4)] = t[4]; A[tri(5, 5)] = t[5];
 #pragma unroll
-    for (int a = 0; a < 8; a++) {
-        const int ua = a < 3 ? a : (a >= 6 ? a - 3 : -1), va = (a >= 3 && a < 6) ? a - 3 : (a >= 6 ? a - 3 : -1);
+    for (int a = 3; a < 6; a++)
 #pragma unroll
-        for (int b = 0; b <= a; b++) {
-            const int ub = b < 3 ? b : (b >= 6 ? b - 3 : -1), vb = (b >= 3 && b < 6) ? b - 3 : (b >= 6 ? b - 3 : -1);
-            double g = 0.0;
-            if (ua >= 0 && ub >= 0) g += Gs[ua * 16 + ub];
-            if (va >= 0 && vb >= 0) g += Gs[(8 + va) * 16 + 8 + vb];
-            A[tri(a, b)] = g;
-        }
-        double w = 0.0;
-        if (ua >= 0) w += Gs[ua * 16 + 5];
-        if (va >= 0) w += Gs[(8 + va) * 16 + 13];
-        v[a] = w;
+        for (int b = 0; b < 3; b++) A[tri(a, b)] = 0.0;
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        A[tri(6, b)] = t[6 + b]; A[tri(7, b)] = t[9 + b];
+        A[tri(6, 3 + b)] = t[12 + b]; A[tri(7, 3 + b)] = t[15 + b];
+        v[b] = t[21 + b]; v[3 + b] = t[24 + b];
     }
-    S = Gs[5 * 16 + 5] + Gs[13 * 16 + 13];
-    wave_lds_sync();      // (one wave per workgroup)
+    A[tri(6, 6)] = t[18]; A[tri(7, 6)] = t[19]; A[tri(7, 7)] = t[20];
+    v[6] = t[27]; v[7] = t[28];
+    S = t[29];
 }
 
 // [OCV-K LMSolverImpl::run] with maxIters = 10, eps = FLT_EPSILON on the 8 free entries
 template <class Pts>
-__device__ void homog_refine(const Pts &pts, int P, int lane, double *tile, double *Gs, double x[8]) {
+__device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, double x[8]) {
     double A[36], v[8], D[8], S;
-    homog_normal_eq(pts, P, lane, x, tile, Gs, A, v, S);
+    homog_normal_eq(pts, P, lane, x, scratch, A, v, S);
 #pragma unroll
     for (int a = 0; a < 8; a++) D[a] = A[tri(a, a)];
     const double Rlo = 0.25, Rhi = 0.75;
@@ -265,7 +273,7 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *tile, doub
         if (Sd < S) {
 #pragma unroll
             for (int a = 0; a < 8; a++) x[a] = xd[a];
-            homog_normal_eq(pts, P, lane, x, tile, Gs, A, v, S);
+            homog_normal_eq(pts, P, lane, x, scratch, A, v, S);
             rmax = rdmax;
         }
         iter++;
@@ -276,7 +284,7 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *tile, doub
 // [OCV-K findHomography(method 0)]: per-axis normalised DLT (smallest eigenvector of LtL by
 // shifted inverse iteration) + LM polish.  Every lane returns the same H.  false = degenerate.
 template <class Pts>
-__device__ bool wave_homography(const Pts &pts, int P, int lane, double *tile, double *Gs, double H[9]) {
+__device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch, double H[9]) {
     double cM0 = 0, cM1 = 0, cm0 = 0, cm1 = 0;
     for (int c0 = 0; c0 < P; c0 += 64) {
         const int p = c0 + lane;
@@ -300,40 +308,47 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *tile, d
     if (fabs(sm0) < DBL_EPS || fabs(sm1) < DBL_EPS || fabs(sM0) < DBL_EPS || fabs(sM1) < DBL_EPS) return false;
     sm0 = P / sm0; sm1 = P / sm1; sM0 = P / sM0; sM1 = P / sM1;
 
-    // LtL = sum Lx Lx^T + Ly Ly^T through the packed 8-column MFMA Gram: Lx touches entries
-    // {0,1,2,6,7,8} of h and Ly {3,4,5,6,7,8} -> [X Y 1 -xX -xY -x 0 0] and [X Y 1 -yX -yY -y 0 0]
-    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    // LtL = sum Lx Lx^T + Ly Ly^T with Lx = [X Y 1 | 0 0 0 | -xX -xY -x], Ly = [0 0 0 | X Y 1 | -yX -yY -y]: with
+    // t = (X, Y, 1) the 45 entries are 24 distinct sums -- t (x) t (twice on the diagonal), -x t (x) t, -y t (x) t,
+    // (x^2 + y^2) t (x) t -- formed per lane and summed over the lanes once (wave_sums_lds)
+    constexpr int LSUMS = 24;
+    double lacc[LSUMS];
+#pragma unroll
+    for (int k = 0; k < LSUMS; k++) lacc[k] = 0.0;
     for (int c0 = 0; c0 < P; c0 += 64) {
         const int p = c0 + lane;
         const bool valid = p < P;
         double Mx, My, mx, my;
         pts.get(valid ? p : P - 1, Mx, My, mx, my);
         const double x = (mx - cm0) * sm0, y = (my - cm1) * sm1;
-        const double X = (Mx - cM0) * sM0, Y = (My - cM1) * sM1;
-        const double ru[8] = {X, Y, 1.0, -x * X, -x * Y, -x, 0.0, 0.0};
-        const double rv[8] = {X, Y, 1.0, -y * X, -y * Y, -y, 0.0, 0.0};
-        tile8_store_rows(tile, lane, ru, rv, valid);
-        wave_lds_sync();      // (one wave per workgroup)
-        tile8_gram(tile, lane, min(64, P - c0), acc0, acc1);
-        wave_lds_sync();      // (one wave per workgroup)
-    }
-    gram_to_lds(Gs, lane, acc0, acc1);
-    wave_lds_sync();      // (one wave per workgroup)
-    double A[45], trace = 0.0;
+        const double one = valid ? 1.0 : 0.0;                 // padding lanes: zero rows
+        const double X = (Mx - cM0) * sM0 * one, Y = (My - cM1) * sM1 * one;
+        const double tt[6] = {X * X, X * Y, Y * Y, X, Y, one};   // t (x) t, packed lower (XX XY YY X1 Y1 11)
+        const double r2 = x * x + y * y;
 #pragma unroll
-    for (int a = 0; a < 9; a++) {
-        const int ua = a < 3 ? a : (a >= 6 ? a - 3 : -1), va = (a >= 3 && a < 6) ? a - 3 : (a >= 6 ? a - 3 : -1);
-#pragma unroll
-        for (int b = 0; b <= a; b++) {
-            const int ub = b < 3 ? b : (b >= 6 ? b - 3 : -1), vb = (b >= 3 && b < 6) ? b - 3 : (b >= 6 ? b - 3 : -1);
-            double g = 0.0;
-            if (ua >= 0 && ub >= 0) g += Gs[ua * 16 + ub];
-            if (va >= 0 && vb >= 0) g += Gs[(8 + va) * 16 + 8 + vb];
-            A[tri(a, b)] = g;
+        for (int k = 0; k < 6; k++) {
+            lacc[k] += tt[k];
+            lacc[6 + k] -= x * tt[k];
+            lacc[12 + k] -= y * tt[k];
+            lacc[18 + k] += r2 * tt[k];
         }
-        trace += A[tri(a, a)];
     }
-    wave_lds_sync();      // (one wave per workgroup)
+    double ls[LSUMS];
+    wave_sums_lds<LSUMS>(lacc, scratch, lane, ls);
+    double A[45], trace = 0.0;
+    // packed-lower index of t_i t_j: (0,0) (1,0) (1,1) (2,0) (2,1) (2,2) == tri(i, j)
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int k = i >= j ? tri(i, j) : tri(j, i);
+            if (i >= j) { A[tri(i, j)] = ls[k]; A[tri(3 + i, 3 + j)] = ls[k]; A[tri(6 + i, 6 + j)] = ls[18 + k]; }
+            A[tri(3 + i, j)] = 0.0;
+            A[tri(6 + i, j)] = ls[6 + k];
+            A[tri(6 + i, 3 + j)] = ls[12 + k];
+        }
+#pragma unroll
+    for (int a = 0; a < 9; a++) trace += A[tri(a, a)];
     // smallest eigenvector: inverse iteration on LtL + mu I (mu keeps the factor positive
     // definite for noise-free data, where the smallest eigenvalue is 0 up to rounding)
     const double mu_shift = 1e-11 * trace;
@@ -381,7 +396,7 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *tile, d
 #pragma unroll
     for (int k = 0; k < 9; k++) H[k] *= s;
     if (P > 4) {
-        homog_refine(pts, P, lane, tile, Gs, H);
+        homog_refine(pts, P, lane, scratch, H);
         H[8] = 1.0;
     }
     bool finite = true;
@@ -396,14 +411,13 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *tile, d
 __global__ __launch_bounds__(64) void k_init_homography(const float *__restrict__ obj, const float *__restrict__ img,
                                                          double *__restrict__ H_out, double *__restrict__ foc, int N,
                                                          int P, int width, int height) {
-    __shared__ __attribute__((aligned(16))) double s_tile[TILE_D];
-    __shared__ __attribute__((aligned(16))) double s_G[256];
+    __shared__ __attribute__((aligned(16))) double s_sums[sums_scratch_doubles(HSUMS)];
     const int i = blockIdx.x, lane = threadIdx.x;
     const RawPoints raw{obj, reinterpret_cast<const float2 *>(img) + (size_t)i * P};
     CachedPoints<RawPoints> pts;
     pts.init(raw, lane, P);
     double H[9];
-    const bool ok = wave_homography(pts, P, lane, s_tile, s_G, H);
+    const bool ok = wave_homography(pts, P, lane, s_sums, H);
     if (lane < 9) H_out[(size_t)9 * i + lane] = ok ? H[lane] : 0.0;
     // [OCV-K cvInitIntrinsicParams2D]
     const double a2 = !width ? 0.5 : (width - 1) * 0.5, a5 = !height ? 0.5 : (height - 1) * 0.5;
@@ -554,11 +568,15 @@ __device__ double view_error(const float *obj, const float2 *img, int P, int lan
     return wave_sum(s);
 }
 
-// JtJ (6x6 packed), Jt e and ||e||^2 of one view through the packed 8-column MFMA Gram
+// JtJ (6x6 packed), Jt e and ||e||^2 of one view: 28 sums over the corners, formed per lane, accumulated over the
+// passes and summed over the lanes once (wave_sums_lds)
+constexpr int VSUMS = 28;
 __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int lane, const double rt[6],
-                                 const double R[9], const double K[9], const double in[NINTR], double *tile, double *Gs,
+                                 const double R[9], const double K[9], const double in[NINTR], double *scratch,
                                  double JtJ[21], double JtErr[6], const FirstPoint &fp) {
-    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    double acc[VSUMS];
+#pragma unroll
+    for (int k = 0; k < VSUMS; k++) acc[k] = 0.0;
     for (int c0 = 0; c0 < P; c0 += 64) {
         const int p = c0 + lane;
         const bool valid = p < P;
@@ -570,34 +588,30 @@ __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int
         double mu[NCOL], mv[NCOL];
         JSUB(0);
         point_rows_K(M, (double)uv.x, (double)uv.y, R, K, rt + 3, in, 0.0, mu, mv, valid ? 1.0 : 0.0);   // padding lanes: zero rows
-        const double ru[8] = {mu[0], mu[1], mu[2], mu[3], mu[4], mu[5], mu[COL_E], 0.0};
-        const double rv[8] = {mv[0], mv[1], mv[2], mv[3], mv[4], mv[5], mv[COL_E], 0.0};
-        tile8_store_rows(tile, lane, ru, rv, true);
-        wave_lds_sync();      // (one wave per workgroup)
         JSUB(1);
-        tile8_gram(tile, lane, min(64, P - c0), acc0, acc1);
-        wave_lds_sync();      // (one wave per workgroup)
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int b = 0; b <= a; b++) acc[tri(a, b)] += mu[a] * mu[b] + mv[a] * mv[b];
+            acc[21 + a] += mu[a] * mu[COL_E] + mv[a] * mv[COL_E];
+        }
+        acc[27] += mu[COL_E] * mu[COL_E] + mv[COL_E] * mv[COL_E];
     }
-    gram_to_lds(Gs, lane, acc0, acc1);
-    wave_lds_sync();      // (one wave per workgroup)
     JSUB(2);
+    double t[VSUMS];
+    wave_sums_lds<VSUMS>(acc, scratch, lane, t);
 #pragma unroll
-    for (int a = 0; a < 6; a++) {
+    for (int k = 0; k < 21; k++) JtJ[k] = t[k];
 #pragma unroll
-        for (int b = 0; b <= a; b++) JtJ[tri(a, b)] = Gs[a * 16 + b] + Gs[(8 + a) * 16 + 8 + b];
-        JtErr[a] = Gs[a * 16 + 6] + Gs[(8 + a) * 16 + 14];
-    }
-    const double e2 = Gs[6 * 16 + 6] + Gs[14 * 16 + 14];
-    wave_lds_sync();      // (one wave per workgroup)
+    for (int a = 0; a < 6; a++) JtErr[a] = t[21 + a];
     JSUB(3);
-    return e2;
+    return t[27];
 }
 
 __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict__ obj, const float *__restrict__ img,
                                                          const double *__restrict__ intr0, double *__restrict__ ext,
                                                          int *__restrict__ fail_count, int N, int P) {
-    __shared__ __attribute__((aligned(16))) double s_tile[TILE_D];
-    __shared__ __attribute__((aligned(16))) double s_G[256];
+    __shared__ __attribute__((aligned(16))) double s_sums[sums_scratch_doubles(HSUMS)];
     const int i = blockIdx.x, lane = threadIdx.x;
     const float2 *img_i = reinterpret_cast<const float2 *>(img) + (size_t)i * P;
 
@@ -627,7 +641,7 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
     ISTAMP(0);
     CachedPoints<NormPoints> cpts;
     cpts.init(pts, lane, P);
-    const bool ok = wave_homography(cpts, P, lane, s_tile, s_G, H);
+    const bool ok = wave_homography(cpts, P, lane, s_sums, H);
     ISTAMP(1);
     if (ok) {
         double h1[3] = {H[0], H[3], H[6]}, h2[3] = {H[1], H[4], H[7]}, h3[3] = {H[2], H[5], H[8]};
@@ -730,7 +744,7 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
         const unsigned long long ts1 = memtime_now();
         if (do_step) t_step += ts1 - ts0;
 #endif
-        if (state == 2) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_tile, s_G, JtJ, JtErr, fp)); n_j++; }
+        if (state == 2) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_sums, JtJ, JtErr, fp)); n_j++; }
         else { errNorm = sqrt(view_error(obj, img_i, P, lane, rt, R, in, fp)); n_e++; }
 #ifdef CCAL_STAMPS
         const unsigned long long ts2 = memtime_now();

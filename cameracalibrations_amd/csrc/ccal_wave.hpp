@@ -162,6 +162,65 @@ __device__ __forceinline__ void tile8_gram(const double *tile, int lane, int npt
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Sums over the 64 lanes of NV per-lane values (NV <= 64), every lane gets all NV totals -- for the small normal
+// equations of the initialisation (28-36 distinct sums per pass over an image's corners), where a 16-wide MFMA Gram
+// computes 256 entries to deliver them and costs a tile store, 14 matrix instructions and a read-back per pass.
+// Transpose-reduce through LDS: lane l stores value j at [j][l] (rows padded to SUMS_LD doubles: consecutive lanes,
+// consecutive addresses on the way in; 16 rows' 16-byte reads on 64 distinct banks on the way out), then lane
+// (j, half) adds up one half of row j (NV <= 32; whole rows by lanes j < NV otherwise) with 16-byte reads, the partial
+// sums go back through LDS and every lane reads them all.  Fixed order of additions: the same bits on every run.
+// scratch: SUMS_LD * NV + 64 doubles, wave-private.
+// ---------------------------------------------------------------------------------------
+constexpr int SUMS_LD = 66;
+constexpr int sums_scratch_doubles(int nv) { return SUMS_LD * nv + 64; }
+
+template <int NV>
+__device__ __forceinline__ void wave_sums_lds(const double (&v)[NV], double *scratch, int lane, double (&out)[NV]) {
+    static_assert(NV >= 1 && NV <= 64, "one row per lane at most");
+#pragma unroll
+    for (int j = 0; j < NV; j++) scratch[j * SUMS_LD + lane] = v[j];
+    wave_lds_sync();
+    double *res = scratch + SUMS_LD * NV;
+    if constexpr (NV <= 32) {
+        const int j = lane & 31, h = lane >> 5;
+        double part = 0.0;
+        if (j < NV) {
+            const double2 *p = reinterpret_cast<const double2 *>(scratch + j * SUMS_LD + 32 * h);
+            double a0 = 0.0, a1 = 0.0;                        // two chains: the adds' latency behind the reads'
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                const double2 d0 = p[q], d1 = p[q + 1];
+                a0 += d0.x; a1 += d1.x;
+                a0 += d0.y; a1 += d1.y;
+            }
+            part = a0 + a1;
+        }
+        res[lane] = part;
+        wave_lds_sync();
+#pragma unroll
+        for (int j2 = 0; j2 < NV; j2++) out[j2] = res[j2] + res[32 + j2];
+    } else {
+        double part = 0.0;
+        if (lane < NV) {
+            const double2 *p = reinterpret_cast<const double2 *>(scratch + lane * SUMS_LD);
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < 32; q += 2) {
+                const double2 d0 = p[q], d1 = p[q + 1];
+                a0 += d0.x; a1 += d1.x;
+                a0 += d0.y; a1 += d1.y;
+            }
+            part = a0 + a1;
+        }
+        res[lane] = part;
+        wave_lds_sync();
+#pragma unroll
+        for (int j2 = 0; j2 < NV; j2++) out[j2] = res[j2];
+    }
+    wave_lds_sync();                                          // the scratch may be overwritten by the next call
+}
+
 // v_mfma_f64_16x16x4_f64 C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg.
 __device__ __forceinline__ void gram_to_lds(double *Gs, int lane, const d4 &acc0, const d4 &acc1) {
 #pragma unroll

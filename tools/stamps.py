@@ -71,7 +71,8 @@ with Solver(0) as s:
     v = [int(x) for x in ib]
     print("k_init_extrinsics (block 7): homography", v[1] - v[0], "cycles; decomposition", v[2] - v[1], "; pose LM", v[3] - v[2],
           "cycles with", v[4], "Jacobian passes,", v[5], "error passes,", v[6], "iterations; homography polish iterations", v[7])
-    print("   last Jacobian pass: rows + tile store", v[12] - v[11], "| MFMA Gram", v[13] - v[12], "| Gram -> LDS -> JtJ, Jte in registers", v[14] - v[13])
+    print("   last Jacobian pass (stamps are approximate: the compiler schedules across them): rows", v[12] - v[11], "| 28 products per lane", v[13] - v[12],
+          "| sums over the lanes through LDS (wave_sums_lds)", v[14] - v[13])
     print("   pose LM split: steps (6x6 solve + rotation)", v[8], "| Jacobian passes", v[9], "| error passes", v[10])
 
     bb = (C.c_uint * (4096 * 4))()
