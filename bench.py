@@ -581,10 +581,13 @@ def roofline_block(N_rank, P, K, sweep_us, n_timed, b2b_us, events_ms_per_step, 
            "fp64_frac": tflops / FP64_PEAK_TFLOPS}
     # traffic: HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/pmc.sh:
     # FETCH_SIZE and WRITE_SIZE in separate passes, both calibrated on a known byte count with this access width)
-    pmc = committed_profile("r02_pmc_traffic_summary.json")
-    if pmc and (N_rank, P) == (1000, 54) and "ccal::k_lm_trial" in pmc:
-        out["traffic"] = float(pmc["ccal::k_lm_trial"]["hbm_bytes_per_launch"])
-        out["traffic_source"] = "committed profile profiles/r02_pmc_traffic_summary.json (not measured in this run)"
+    for shape, names in (((1000, 54), ("r03_pmc_traffic_summary.json", "r02_pmc_traffic_summary.json")),
+                         ((10000, 150), ("r03_c5_pmc_traffic_summary.json",))):
+        for name in names:
+            pmc = committed_profile(name)
+            if pmc and (N_rank, P) == shape and "ccal::k_lm_trial" in pmc and out["traffic"] is None:
+                out["traffic"] = float(pmc["ccal::k_lm_trial"]["hbm_bytes_per_launch"])
+                out["traffic_source"] = f"committed profile profiles/{name} (rocprofv3 PMC passes of this command, not measured in this run)"
     floor_us, terms = latency_floor(P)
     if N_rank > 1024:      # more images than SIMDs: a launch is FP64 throughput, not one image's latency chain
         terms = {"boundary": KERNEL_BOUNDARY_US, "fp64_flop_at_vector_peak": flops / (FP64_PEAK_TFLOPS * 1e6)}

@@ -129,39 +129,6 @@ __device__ __forceinline__ void tile_gram(const double *tile, int lane, int npts
     }
 }
 
-// Packed variant for systems of at most 8 columns (the 6-parameter pose polish: J | e): one corner
-// becomes ONE 16-wide tile row, its u-row in columns 0-7 and its v-row in columns 8-15, so the
-// product is [[Gu, X], [X^T, Gv]] and the wanted Gram matrix is Gu + Gv: half the LDS traffic and
-// half the MFMA steps of the 16-column form.
-constexpr int TILE8_LD = 18;          // doubles per corner: 16 + 2 pad (144 B, 16-B aligned)
-
-__device__ __forceinline__ void tile8_store_rows(double *tile, int lane, const double mu[8], const double mv[8],
-                                                 bool valid) {
-    double2 *dst = reinterpret_cast<double2 *>(tile + lane * TILE8_LD);
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        dst[c] = valid ? make_double2(mu[2 * c], mu[2 * c + 1]) : make_double2(0.0, 0.0);
-        dst[4 + c] = valid ? make_double2(mv[2 * c], mv[2 * c + 1]) : make_double2(0.0, 0.0);
-    }
-}
-
-__device__ __forceinline__ void tile8_gram(const double *tile, int lane, int npts, d4 &acc0, d4 &acc1) {
-    const int rd_off = (lane >> 4) * TILE8_LD + (lane & 15);   // k-step s: corners 4s .. 4s+3
-    const int nsteps = (((npts + 3) >> 2) + 1) & ~1;            // rounded up to even (zero rows beyond npts)
-    // all sixteen operands are requested before the first MFMA waits for one (every one of the 64 corner rows of
-    // the tile is written, zeros beyond npts): one LDS latency per pass instead of one per pair of k-steps
-    double a[16];
-#pragma unroll
-    for (int s = 0; s < 16; s++) a[s] = tile[s * 4 * TILE8_LD + rd_off];
-#pragma unroll
-    for (int s = 0; s < 16; s += 2) {
-        if (s < nsteps) {                                       // wave-uniform
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], a[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s + 1], a[s + 1], acc1, 0, 0, 0);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // Sums over the 64 lanes of NV per-lane values (NV <= 64), every lane gets all NV totals -- for the small normal
 // equations of the initialisation (28-36 distinct sums per pass over an image's corners), where a 16-wide MFMA Gram
