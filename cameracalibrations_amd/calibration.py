@@ -92,38 +92,52 @@ class Calibration:
 
 class _MapBatch:
     """Buffer of point-wise map calls (Calibration.batch): `b(x, i)` queues one point and hands back the array its result
-    will be written to; leaving the `with` block (or `flush()`) evaluates everything queued in at most two device calls
-    (ccal_project_many / ccal_unproject_many with one point per pose entry).  A loop over points like the reference's
-    round-trip metric (src/buildcalibrations.jl:53-58) then costs two calls instead of two per point."""
+    will be written to (a row of a buffer that is filled when the queue is evaluated); leaving the `with` block (or
+    `flush()`) evaluates everything queued in at most two device calls (ccal_project_many / ccal_unproject_many with one
+    point per pose entry).  A loop over points like the reference's round-trip metric (src/buildcalibrations.jl:53-58)
+    then costs two calls instead of two per point."""
+    _CHUNK = 256
 
     def __init__(self, c):
         self._c = c
-        self._q = {3: ([], [], []), 2: ([], [], [])}       # width of the input -> (points, pose indices, outputs)
+        self._n_poses = len(c.rvecs)
+        self._first = c._index(None) if any("extrinsic" in f for f in c.files) else None
+        # width of the input -> [points, pose indices, result chunks (CHUNK x output width), queued count]
+        self._q = {3: [[], [], [], 0], 2: [[], [], [], 0]}
 
     def __call__(self, x, extrinsic_index=None):
-        i = self._c._index(extrinsic_index)
-        x = np.asarray(x, dtype=np.float64)
-        if x.shape not in ((3,), (2,)):
-            raise TypeError("expected an XYZ (3-vector) or RowCol (2-vector)")
-        pts, idx, outs = self._q[x.shape[0]]
-        out = np.full(5 - x.shape[0], np.nan)
-        pts.append(x)
-        idx.append(i)
-        outs.append(out)
-        return out
+        if extrinsic_index is None:
+            i = self._c._index(None) if self._first is None else self._first
+        else:
+            i = int(extrinsic_index) - 1                   # the reference API is 1-based
+            if not 0 <= i < self._n_poses:
+                raise IndexError(f"extrinsic index {extrinsic_index} out of range 1:{self._n_poses}")
+        try:
+            q = self._q[len(x)]
+        except (KeyError, TypeError):
+            raise TypeError("expected an XYZ (3-vector) or RowCol (2-vector)") from None
+        n = q[3]
+        if n % self._CHUNK == 0 and n // self._CHUNK == len(q[2]):
+            q[2].append(np.full((self._CHUNK, 5 - len(x)), np.nan))
+        q[0].append(x)
+        q[1].append(i)
+        q[3] = n + 1
+        return q[2][n // self._CHUNK][n % self._CHUNK]
 
     def flush(self):
         c = self._c
         s = _shared_solver(c.device)
         for w, fn in ((3, s.project_many), (2, s.unproject_many)):
-            pts, idx, outs = self._q[w]
-            if not pts:
+            pts, idx, chunks, n = self._q[w]
+            if not n:
                 continue
-            x = np.array(pts, dtype=np.float64).reshape(len(pts), 1, w)
+            x = np.array(pts, dtype=np.float64).reshape(n, 1, w)
             res = fn(x, c.f, c.c, c.k, c.rvecs[idx], c.tvecs[idx], c.checker_size)[:, 0, :]
-            for o, r in zip(outs, res):
-                o[:] = r
-            self._q[w] = ([], [], [])
+            for k, ch in enumerate(chunks):                  # rows already handed out are views of these chunks
+                m = min(self._CHUNK, n - k * self._CHUNK)
+                if m > 0:
+                    ch[:m] = res[k * self._CHUNK:k * self._CHUNK + m]
+            self._q[w] = [[], [], [], 0]
 
     def __enter__(self):
         return self
