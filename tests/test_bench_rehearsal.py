@@ -1,6 +1,7 @@
-"""bench.py end to end on the GPU box: the single-GPU line the driver records, and the N-rank launch
-(`python -m torch.distributed.run ... bench.py --gpus N`) rehearsed with the ranks sharing the one GPU
-(`--share-gpu`: gloo rendezvous instead of RCCL, everything else the same code path)."""
+"""bench.py end to end on the GPU box: the single-GPU line the driver records, and the N-rank launch -- through a
+launcher (`python -m torch.distributed.run ... bench.py --gpus 2`) and without one (`python bench.py --gpus 4`: bench.py
+starts its own ranks) -- rehearsed with the ranks sharing the one GPU (`--share-gpu`: gloo rendezvous instead of RCCL,
+one exchange workgroup per rank instead of the fused exchange, everything else the same code path)."""
 import json
 import os
 import socket
