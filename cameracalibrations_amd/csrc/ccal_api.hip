@@ -515,8 +515,7 @@ static LmInit make_init(const ccal_ctx *c) {
 // read back what the host mirrors and the failure flags of the initialisation kernels: enqueue ...
 static int finish_init_enqueue(ccal_ctx *c) {
     double *h_intr = reinterpret_cast<double *>(c->h_flags + 4);   // pinned staging (flags: ints 0..3)
-    HIPCHK(hipMemcpyAsync(h_intr, c->d_intr0, sizeof(double) * 9, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_flags, c->d_fail, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(launch_init_readback(c->stream, c->d_intr0, c->d_fail, h_intr, c->h_flags));
     return CCAL_OK;
 }
 

@@ -64,6 +64,8 @@ hipError_t launch_map_forward(hipStream_t stream, const double *xyz, long long x
 hipError_t launch_map_inverse(hipStream_t stream, const double *rc, double *xyz, int M, int N, const MapIntr &in,
                               const double *rt);
 hipError_t launch_signal(hipStream_t stream, unsigned long long *flag, unsigned long long value);   // pinned completion word
+// intr[9], fail[4] (device) -> pinned host memory, by a kernel on `stream`
+hipError_t launch_init_readback(hipStream_t stream, const double *intr, const int *fail, double *host_intr, int *host_fail);
 struct RectPar { double v[16]; };   // f0 f1 c0 c1 k rvec(3) tvec(3) checker_size ratio index_offset, by value
 hipError_t launch_rectify(hipStream_t stream, const uint8_t *img, int rows, int cols, int ch, long long sr, long long sc,
                           long long sk, int a0, int b0, int out_rows, int out_cols, const RectPar &par, uint8_t *out);

@@ -194,6 +194,18 @@ hipError_t launch_rectify(hipStream_t stream, const uint8_t *img, int rows, int 
 __global__ void k_signal(unsigned long long *flag, unsigned long long value) {
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// read-back of the initialisation's nine intrinsic values and four failure words straight into pinned host memory by a
+// kernel (one launch instead of two copy commands); the completion word that follows it (k_signal) releases them
+__global__ void k_init_readback(const double *__restrict__ intr, const int *__restrict__ fail, double *host_intr, int *host_fail) {
+    const int t = threadIdx.x;
+    if (t < 9) __hip_atomic_store(host_intr + t, intr[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (t < 13) __hip_atomic_store(host_fail + (t - 9), fail[t - 9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_init_readback(hipStream_t stream, const double *intr, const int *fail, double *host_intr, int *host_fail) {
+    hipLaunchKernelGGL(k_init_readback, dim3(1), dim3(64), 0, stream, intr, fail, host_intr, host_fail);
+    return hipGetLastError();
+}
+
 hipError_t launch_signal(hipStream_t stream, unsigned long long *flag, unsigned long long value) {
     hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, stream, flag, value);
     return hipGetLastError();
