@@ -23,7 +23,7 @@
 namespace ccal {
 
 #ifdef CCAL_STAMPS
-__device__ unsigned long long g_init_stamps[16];
+__device__ unsigned long long g_init_stamps[32];
 __device__ unsigned int g_init_blk[4096 * 4];   // per block: total cycles, homography polish iters, pose LM iters, Jacobian passes
 #define IBLK(j, v) do { if (blockIdx.x < 4096 && threadIdx.x == 0) g_init_blk[blockIdx.x * 4 + (j)] = (unsigned int)(v); } while (0)
 static __device__ __forceinline__ unsigned long long memtime_now() {
@@ -50,8 +50,18 @@ static __device__ __forceinline__ unsigned long long memtime_now() {
         }                                                                                     \
     } while (0)
 #define ICOUNT(i, v) do { if (blockIdx.x == 7 && threadIdx.x == 0) g_init_stamps[i] = (unsigned long long)(v); } while (0)
+#define HSTAMP(i)                                                                             \
+    do {                                                                                      \
+        if (blockIdx.x == 7 && threadIdx.x == 0) {                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            unsigned long long t_;                                                            \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");         \
+            g_init_stamps[16 + (i)] = t_;                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+        }                                                                                     \
+    } while (0)
 hipError_t debug_read_init_stamps(unsigned long long *out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_init_stamps), sizeof(unsigned long long) * 16);
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_init_stamps), sizeof(unsigned long long) * 32);
 }
 hipError_t debug_read_init_blocks(unsigned int *out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_init_blk), sizeof(unsigned int) * 4096 * 4);
@@ -61,6 +71,7 @@ hipError_t debug_read_init_blocks(unsigned int *out) {
 #define JSUB(i) do { } while (0)
 #define ISTAMP(i) do { } while (0)
 #define ICOUNT(i, v) do { } while (0)
+#define HSTAMP(i) do { } while (0)
 #endif
 
 constexpr double DBL_EPS = 2.220446049250313e-16;
@@ -215,7 +226,9 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, d
     double lambda = 1.0, lc = 0.75;
     double rmax;
     (void)homog_error(pts, P, lane, x, rmax);
+    HSTAMP(6);
     for (int iter = 0;;) {
+        HSTAMP(7);
         double Ap[36], d[8], xd[8];
 #pragma unroll
         for (int k = 0; k < 36; k++) Ap[k] = A[k];
@@ -227,8 +240,10 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, d
         bwd_subst<8>(Ap, ipv, d);
 #pragma unroll
         for (int a = 0; a < 8; a++) xd[a] = x[a] - d[a];
+        HSTAMP(8);
         double rdmax;
         const double Sd = homog_error(pts, P, lane, xd, rdmax);
+        HSTAMP(9);
         double dS = 0.0, dv = 0.0, dmax = 0.0;          // dS = d . (2 v - A d)
 #pragma unroll
         for (int a = 0; a < 8; a++) {
@@ -270,12 +285,14 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, d
             }
             lambda *= nu;
         }
+        HSTAMP(10);
         if (Sd < S) {
 #pragma unroll
             for (int a = 0; a < 8; a++) x[a] = xd[a];
             homog_normal_eq(pts, P, lane, x, scratch, A, v, S);
             rmax = rdmax;
         }
+        HSTAMP(11);
         iter++;
         if (!(iter < 10 && dmax >= FLT_EPS && rmax >= FLT_EPS)) { ICOUNT(7, iter); IBLK(1, iter); break; }
     }
@@ -285,6 +302,7 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, d
 // shifted inverse iteration) + LM polish.  Every lane returns the same H.  false = degenerate.
 template <class Pts>
 __device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch, double H[9]) {
+    HSTAMP(0);
     double cM0 = 0, cM1 = 0, cm0 = 0, cm1 = 0;
     for (int c0 = 0; c0 < P; c0 += 64) {
         const int p = c0 + lane;
@@ -308,6 +326,7 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch
     if (fabs(sm0) < DBL_EPS || fabs(sm1) < DBL_EPS || fabs(sM0) < DBL_EPS || fabs(sM1) < DBL_EPS) return false;
     sm0 = P / sm0; sm1 = P / sm1; sM0 = P / sM0; sM1 = P / sM1;
 
+    HSTAMP(1);
     // LtL = sum Lx Lx^T + Ly Ly^T with Lx = [X Y 1 | 0 0 0 | -xX -xY -x], Ly = [0 0 0 | X Y 1 | -yX -yY -y]: with
     // t = (X, Y, 1) the 45 entries are 24 distinct sums -- t (x) t (twice on the diagonal), -x t (x) t, -y t (x) t,
     // (x^2 + y^2) t (x) t -- formed per lane and summed over the lanes once (wave_sums_lds)
@@ -349,6 +368,7 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch
         }
 #pragma unroll
     for (int a = 0; a < 9; a++) trace += A[tri(a, a)];
+    HSTAMP(2);
     // smallest eigenvector: inverse iteration on LtL + mu I (mu keeps the factor positive
     // definite for noise-free data, where the smallest eigenvalue is 0 up to rounding)
     const double mu_shift = 1e-11 * trace;
@@ -377,6 +397,7 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch
         }
         if (change < 1.0e-15) break;          // converged to rounding (typically 3-4 iterations)
     }
+    HSTAMP(3);
     // H = invHnorm * H0 * Hnorm2, scaled so that H[8] = 1
     const double i0 = 1.0 / sm0, i1 = 1.0 / sm1;
     double T[9];
@@ -395,10 +416,12 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch
     const double s = 1.0 / H[8];
 #pragma unroll
     for (int k = 0; k < 9; k++) H[k] *= s;
+    HSTAMP(4);
     if (P > 4) {
         homog_refine(pts, P, lane, scratch, H);
         H[8] = 1.0;
     }
+    HSTAMP(5);
     bool finite = true;
 #pragma unroll
     for (int k = 0; k < 9; k++) finite = finite && (fabs(H[k]) < 1.0e300);

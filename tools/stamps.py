@@ -65,7 +65,7 @@ with Solver(0) as s:
                "what": "s_memtime stamps of wave 0 of one workgroup in the last sweeping launch of a solve (diagnostic build, "
                        "-DCCAL_STAMPS: the stamps and their scheduling barriers add roughly 5-10 % to the wave's cycles)"},
               open(os.path.join(ROOT, "gpurun_out", "wave_stamps_block%d.json" % BLOCK), "w"), indent=1)
-    ib = (C.c_ulonglong * 16)()
+    ib = (C.c_ulonglong * 32)()
     L.ccal_debug_init_stamps.restype = C.c_int
     L.ccal_debug_init_stamps(ib)
     v = [int(x) for x in ib]
@@ -73,6 +73,10 @@ with Solver(0) as s:
           "cycles with", v[4], "Jacobian passes,", v[5], "error passes,", v[6], "iterations; homography polish iterations", v[7])
     print("   last Jacobian pass (stamps are approximate: the compiler schedules across them): rows", v[12] - v[11], "| 28 products per lane", v[13] - v[12],
           "| sums over the lanes through LDS (wave_sums_lds)", v[14] - v[13])
+    h = v[16:28]
+    print("   homography: centroids + scales", h[1] - h[0], "| DLT sums", h[2] - h[1], "| 9x9 factor + inverse iteration", h[3] - h[2], "| compose", h[4] - h[3],
+          "| polish", h[5] - h[4], "= first normal equations + error", h[6] - h[4], "+ iterations; last iteration: 8x8 solve", h[8] - h[7],
+          "| error pass", h[9] - h[8], "| gain ratio + lambda", h[10] - h[9], "| normal equations", h[11] - h[10])
     print("   pose LM split: steps (6x6 solve + rotation)", v[8], "| Jacobian passes", v[9], "| error passes", v[10])
 
     bb = (C.c_uint * (4096 * 4))()
