@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CCAL_VERSION 100 /* 0.1.0 */
+#define CCAL_VERSION 101 /* 0.1.1: ccal_stats.solve_kernels_us, ccal_fit, ccal_set_graph, ccal_p2p_set_exchange, ccal_device_uuid */
 
 /* status codes */
 #define CCAL_OK            0
