@@ -900,6 +900,17 @@ def test_one_pipeline_fit_equals_the_stages():
             s.set_problem(wl.obj, wl.n_images, wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=REF[0], eps=REF[1])
             s.set_image_points(torch.from_numpy(wl.img).cuda())
             assert s.fit() == st and np.array_equal(s.result()["intr"], a["intr"])
+    # with an intrinsic guess (CALIB_USE_INTRINSIC_GUESS) the pipeline starts at the pose initialisation
+    wl = syn.named_workload("C2", n_images=11)
+    guess = np.r_[wl.intr_true[:4] * 1.01, 0.0, 0.0, 0.0, 0.0, 0.0]
+    with Solver(0) as s:
+        s.set_problem(wl.obj, wl.n_images, wl.image_size, aspect=wl.aspect, flags=wl.flags | syn.USE_INTRINSIC_GUESS)
+        s.set_image_points(wl.img)
+        with pytest.raises(F.CcalError):
+            s.fit()                                            # no guess supplied yet
+        st, a = s.calibrate(init_intr=guess)
+        s.set_intrinsics(guess)
+        assert s.fit() == st and np.array_equal(s.result()["intr"], a["intr"]) and np.array_equal(s.result()["tvecs"], a["tvecs"])
     wl = syn.named_workload("C2", n_images=5)
     bad = wl.img.copy()
     bad[2] = bad[2, 0]                                         # one image with all corners in one spot: no homography
