@@ -381,18 +381,21 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
         c->p_cap = P;
     }
     HIPCHK(hipMemcpyAsync(c->d_obj, obj, sizeof(float) * 3 * P, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_blk, 0, sizeof(double) * 2 * (size_t)N * BLK, c->stream));
-    HIPCHK(hipMemsetAsync(c->d_ext0, 0, sizeof(double) * (size_t)N * EXT, c->stream));
+    // (no clearing of blk / ext0: a solve's first launch reads the six pose words of ext0 and nothing of blk, and every sweep
+    //  writes its images' blocks whole -- two memset launches per call were a tenth of a reference-sized fit)
     if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));   // `obj` may be released by the caller after return
     c->P = P; c->N = N; c->width = width; c->height = height; c->aspect = aspect; c->flags = flags;
     c->max_iter = max_iter; c->eps = eps;
     const int sweep_grid = std::min(lm_sweep_blocks(N), lm_max_grid());
+    const int old_R = c->acc_R;
     c->acc_R = lm_acc_replicas(sweep_grid);
     if (const char *r = getenv("CCAL_ACC_REPLICAS")) {      // experiments: 1, 2, 4, ... 64
         const int v = atoi(r);
         if (v >= 1 && v <= ACC_MAX_REPLICAS && (v & (v - 1)) == 0 && (sweep_grid + v - 1) / v <= 2000) c->acc_R = v;
     }
-    c->acc_dirty = true;               // the buffer layout depends on the replica count
+    // the buffer layout depends on the replica count; with the same count the last solve's terminating launch has left
+    // every buffer cleared (acc_dirty is false then) and the next solve needs no 0.5 MB memset
+    if (c->acc_R != old_R) c->acc_dirty = true;
     c->have_problem = true;
     c->have_img = c->have_intr = c->have_ext = c->have_result = false;
     c->d_img = nullptr;
