@@ -754,6 +754,24 @@ def test_c3_sharded_over_ranks_matches_oracle(world, transport):
     assert np.abs(rv - ro["rvecs"]).max() < 1e-5 and np.abs(tv - ro["tvecs"]).max() < 1e-4
 
 
+def test_calibrate_multi_reports_a_degenerate_shard_and_recovers():
+    """One shard of a multi-shard fit holds an image without a homography (all corners in one spot): the call comes back
+    with the initialisation's error (no hang: every stage of every shard was enqueued before any wait), and the cached
+    contexts serve the next, healthy call."""
+    from cameracalibrations_amd import _ffi as F
+    from cameracalibrations_amd.solver import calibrate_multi
+    wl = syn.named_workload("C2", n_images=24)
+    bad = wl.img.copy()
+    bad[17] = bad[17, 0]
+    for devices in ([0, 0, 0], [0] * 8):
+        with pytest.raises(F.CcalError) as e:
+            calibrate_multi(wl.obj, bad, wl.image_size, devices, aspect=wl.aspect, flags=wl.flags)
+        assert e.value.code in (F.E_DEGENERATE, F.E_NONFINITE), e.value
+        st, r = calibrate_multi(wl.obj, wl.img, wl.image_size, devices, aspect=wl.aspect, flags=wl.flags)
+        assert st == 0 and 0.05 < r["rms"] < 0.3
+    F.lib().ccal_thread_cleanup()
+
+
 def _check_against_oracle(r, ro):
     assert r["iters"] == ro["iters"] and abs(r["rms"] - ro["rms"]) < 1e-8
     assert np.abs(r["intr"][:4] - ro["intr"][:4]).max() / ro["intr"][1] < 1e-6 and np.abs(r["intr"][4:] - ro["intr"][4:]).max() < 1e-5
