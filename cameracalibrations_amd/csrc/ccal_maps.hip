@@ -127,24 +127,22 @@ __global__ __launch_bounds__(256) void k_errors(const double *__restrict__ obj, 
     if (tid < 4) partials[(size_t)4 * i + tid] = s_acc[tid][0];
 }
 
-// fixed-order sum of the per-image partials [4,N] -> out[4]
-// (image order, one running sum per metric: the same bits for any N; the partials come through LDS in coalesced chunks
-//  so that the four sequential sums are add-bound, not one memory round trip per image)
+// fixed-order sum of the per-image partials [4,N] -> out[4]: thread (metric m, slice s) adds the images i = s, s + 64,
+// s + 128, ... in order, the 64 slice sums of a metric are then added in slice order (one thread per metric) -- the same
+// bits on every run for a given N, coalesced 2-KB reads, N / 64 dependent adds instead of N
 __global__ __launch_bounds__(256) void k_errors_reduce(const double *__restrict__ partials, double *__restrict__ out,
                                                        int N) {
-    constexpr int CHUNK = 1024;                       // images per staging round (32 KB of static LDS)
-    __shared__ double buf[4 * CHUNK];
-    const int tid = threadIdx.x;
+    __shared__ double s_slice[64][4];
+    const int tid = threadIdx.x, m = tid & 3, sl = tid >> 2;
     double s = 0.0;
-    for (int i0 = 0; i0 < N; i0 += CHUNK) {
-        const int n = min(CHUNK, N - i0);
-        for (int k = tid; k < 4 * n; k += 256) buf[k] = partials[(size_t)4 * i0 + k];
-        __syncthreads();
-        if (tid < 4)
-            for (int i = 0; i < n; i++) s += buf[4 * i + tid];
-        __syncthreads();
+    for (int i = sl; i < N; i += 64) s += partials[(size_t)4 * i + m];
+    s_slice[sl][m] = s;
+    __syncthreads();
+    if (tid < 4) {
+        double t = 0.0;
+        for (int k = 0; k < 64; k++) t += s_slice[k][tid];
+        out[tid] = t;
     }
-    if (tid < 4) out[tid] = s;
 }
 
 // Rectified view of one image (reference src/plot_calibration.jl:15-22,40: `warp(img, tform, axs)` with
