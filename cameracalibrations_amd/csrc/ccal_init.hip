@@ -570,26 +570,8 @@ __device__ __forceinline__ void rodrigues_inv(const double R[9], double r[3]) {
     r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
 }
 
-// residual-only / residual+Jacobian pass of the per-view LM
+// residual + Jacobian pass of the per-view LM
 struct FirstPoint { float m[3]; float2 uv; };      // this lane's point of the first pass (index min(lane, P - 1)), kept in registers
-
-__device__ double view_error(const float *obj, const float2 *img, int P, int lane, const double rt[6],
-                             const double R[9], const double in[NINTR], const FirstPoint &fp) {
-    double s = 0.0;
-    for (int c0 = 0; c0 < P; c0 += 64) {
-        const int p = c0 + lane;
-        if (p < P) {
-            const bool first = c0 == 0;
-            const double M[3] = {(double)(first ? fp.m[0] : obj[3 * p]), (double)(first ? fp.m[1] : obj[3 * p + 1]),
-                                 (double)(first ? fp.m[2] : obj[3 * p + 2])};
-            const float2 uv = first ? fp.uv : img[p];
-            double eu, ev;
-            point_residual(M, (double)uv.x, (double)uv.y, R, rt + 3, in, eu, ev);
-            s += eu * eu + ev * ev;
-        }
-    }
-    return wave_sum(s);
-}
 
 // JtJ (6x6 packed), Jt e and ||e||^2 of one view: 28 sums over the corners, formed per lane, accumulated over the
 // passes and summed over the lanes once (wave_sums_lds)
@@ -720,6 +702,15 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
         fp.m[0] = obj[3 * p0]; fp.m[1] = obj[3 * p0 + 1]; fp.m[2] = obj[3 * p0 + 2];
         fp.uv = img_i[p0];
     }
+    // A trial point is evaluated with the Jacobian pass straight away (CvLevMarq evaluates the error alone and, on
+    // acceptance, the Jacobian at the same point in a second pass): steps are accepted almost without exception (2 rejections
+    // in the 1000 views of C3), so the trial point's normal equations are the next step's and the error-only pass is saved
+    // -- 0.6 k cycles per iteration of the views the launch waits for (the ones that run OpenCV's 20-iteration cap).
+    // Same decisions, same points; a rejected trial simply discards its normal equations.  Since the normal equations
+    // became per-lane products + one LDS reduce the Jacobian pass is 2.7 k cycles; with round 2's 4.1 k this lost.
+    // (tools/init_timing.py, one box: extrinsics stage 95.1 -> 87.5 us on C3, 530 -> 499 us on C5.)
+    double JtJ_c[21], JtErr_c[6];
+    bool have_cand = false;
     for (int guard = 0; ok && guard < 20 * 24; guard++) {
         bool do_step = false;
         if (state == 1) {
@@ -733,6 +724,7 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
         } else {
             if (errNorm > prevErrNorm && ++lambdaLg10 <= 16) {
                 do_step = true;
+                have_cand = false;
             } else {
                 lambdaLg10 = max(lambdaLg10 - 1, -16);
                 double num = 0.0, den = 0.0;
@@ -740,7 +732,18 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
                 for (int k = 0; k < 6; k++) { num += (rt[k] - prev[k]) * (rt[k] - prev[k]); den += prev[k] * prev[k]; }
                 if (++iters >= 20 || sqrt(num) / sqrt(den) < FLT_EPS) break;
                 prevErrNorm = errNorm;
-                state = 2;
+                if (have_cand) {
+                    // the accepted point's normal equations are already here: CALC_J's bookkeeping and the step at once
+#pragma unroll
+                    for (int k = 0; k < 21; k++) JtJ[k] = JtJ_c[k];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) { JtErr[k] = JtErr_c[k]; prev[k] = rt[k]; }
+                    have_cand = false;
+                    do_step = true;
+                    state = 3;
+                } else {
+                    state = 2;
+                }
             }
         }
 #ifdef CCAL_STAMPS
@@ -768,7 +771,7 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
         if (do_step) t_step += ts1 - ts0;
 #endif
         if (state == 2) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_sums, JtJ, JtErr, fp)); n_j++; }
-        else { errNorm = sqrt(view_error(obj, img_i, P, lane, rt, R, in, fp)); n_e++; }
+        else { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_sums, JtJ_c, JtErr_c, fp)); have_cand = true; n_e++; }
 #ifdef CCAL_STAMPS
         const unsigned long long ts2 = memtime_now();
         if (state == 2) t_jac += ts2 - ts1; else t_err += ts2 - ts1;

@@ -70,22 +70,22 @@ with Solver(0) as s:
     L.ccal_debug_init_stamps(ib)
     v = [int(x) for x in ib]
     print("k_init_extrinsics (block 7): homography", v[1] - v[0], "cycles; decomposition", v[2] - v[1], "; pose LM", v[3] - v[2],
-          "cycles with", v[4], "Jacobian passes,", v[5], "error passes,", v[6], "iterations; homography polish iterations", v[7])
+          "cycles with", v[4], "Jacobian passes at accepted points,", v[5], "at trial points,", v[6], "iterations; homography polish iterations", v[7])
     print("   last Jacobian pass (stamps are approximate: the compiler schedules across them): rows", v[12] - v[11], "| 28 products per lane", v[13] - v[12],
           "| sums over the lanes through LDS (wave_sums_lds)", v[14] - v[13])
     h = v[16:28]
     print("   homography: centroids + scales", h[1] - h[0], "| DLT sums", h[2] - h[1], "| 9x9 factor + inverse iteration", h[3] - h[2], "| compose", h[4] - h[3],
           "| polish", h[5] - h[4], "= first normal equations + error", h[6] - h[4], "+ iterations; last iteration: 8x8 solve", h[8] - h[7],
           "| error pass", h[9] - h[8], "| gain ratio + lambda", h[10] - h[9], "| normal equations", h[11] - h[10])
-    print("   pose LM split: steps (6x6 solve + rotation)", v[8], "| Jacobian passes", v[9], "| error passes", v[10])
+    print("   pose LM split: steps (6x6 solve + rotation)", v[8], "| passes at accepted points", v[9], "| passes at trial points", v[10])
 
     bb = (C.c_uint * (4096 * 4))()
     L.ccal_debug_init_blocks.restype = C.c_int
     L.ccal_debug_init_blocks(bb)
     b = np.array(bb[:], dtype=np.int64).reshape(4096, 4)[:1000]
     print("per-image k_init_extrinsics cycles: min %d median %d p90 %d max %d" % (b[:, 0].min(), np.median(b[:, 0]), np.percentile(b[:, 0], 90), b[:, 0].max()))
-    for j, n in ((1, "homography polish iters"), (2, "pose LM iters"), (3, "pose error passes")):
+    for j, n in ((1, "homography polish iters"), (2, "pose LM iters"), (3, "pose trial-point passes")):
         print("  ", n, np.bincount(b[:, j]).tolist())
     slow = np.argsort(b[:, 0])[-8:]
-    print("   slowest images: (cycles, pose iters, error passes)", [(int(b[i, 0]), int(b[i, 2]), int(b[i, 3])) for i in slow])
-    print("   rejected pose steps (error passes - iterations): total", int((b[:, 3] - b[:, 2]).sum()), "max per image", int((b[:, 3] - b[:, 2]).max()))
+    print("   slowest images: (cycles, pose iters, trial-point passes)", [(int(b[i, 0]), int(b[i, 2]), int(b[i, 3])) for i in slow])
+    print("   rejected pose steps (trial-point passes - iterations): total", int((b[:, 3] - b[:, 2]).sum()), "max per image", int((b[:, 3] - b[:, 2]).max()))
