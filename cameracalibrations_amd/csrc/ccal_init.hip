@@ -149,23 +149,6 @@ __device__ __forceinline__ void homog_point(const double h[8], double Mx, double
     ev = yi - my;
 }
 
-template <class Pts>
-__device__ double homog_error(const Pts &pts, int P, int lane, const double h[8], double &rmax) {
-    double s = 0.0, m = 0.0;
-    for (int c0 = 0; c0 < P; c0 += 64) {
-        const int p = c0 + lane;
-        if (p < P) {
-            double Mx, My, mx, my, eu, ev, ww, xi, yi;
-            pts.get(p, Mx, My, mx, my);
-            homog_point(h, Mx, My, mx, my, eu, ev, ww, xi, yi);
-            s += eu * eu + ev * ev;
-            m = fmax(m, fmax(fabs(eu), fabs(ev)));
-        }
-    }
-    rmax = wave_max(m);
-    return wave_sum(s);
-}
-
 // A (8x8 packed lower) = J^T J, v = J^T r, S = r^T r at h.  The u-row of a correspondence touches only parameters
 // {0,1,2,6,7} and the v-row only {3,4,5,6,7}, and both carry the same first three entries (Mx w, My w, w): of the 45
 // entries 30 are distinct non-zero sums -- formed per lane, accumulated over the passes and summed over the lanes once
@@ -173,8 +156,8 @@ __device__ double homog_error(const Pts &pts, int P, int lane, const double h[8]
 constexpr int HSUMS = 30;
 template <class Pts>
 __device__ void homog_normal_eq(const Pts &pts, int P, int lane, const double h[8], double *scratch,
-                                double A[36], double v[8], double &S) {
-    double acc[HSUMS];
+                                double A[36], double v[8], double &S, double &rmax) {
+    double acc[HSUMS], emax = 0.0;
 #pragma unroll
     for (int k = 0; k < HSUMS; k++) acc[k] = 0.0;
     for (int c0 = 0; c0 < P; c0 += 64) {
@@ -186,6 +169,7 @@ __device__ void homog_normal_eq(const Pts &pts, int P, int lane, const double h[
         const double vm = valid ? 1.0 : 0.0;                  // padding lanes: zero rows
         const double w = ww * vm, p = Mx * w, q = My * w;
         eu *= vm; ev *= vm;
+        emax = fmax(emax, fmax(fabs(eu), fabs(ev)));
         const double ux = -p * xi, uy = -q * xi, vx = -p * yi, vy = -q * yi;
         acc[0] += p * p; acc[1] += p * q; acc[2] += q * q; acc[3] += p * w; acc[4] += q * w; acc[5] += w * w;
         acc[6] += ux * p; acc[7] += ux * q; acc[8] += ux * w; acc[9] += uy * p; acc[10] += uy * q; acc[11] += uy * w;
@@ -196,6 +180,7 @@ __device__ void homog_normal_eq(const Pts &pts, int P, int lane, const double h[
         acc[29] += eu * eu + ev * ev;
     }
     double t[HSUMS];
+    rmax = wave_max(emax);
     wave_sums_lds<HSUMS>(acc, scratch, lane, t);
     // (0..2)^2 and (3..5)^2 blocks are the same sums; (3..5) x (0..2) is structurally zero
     A[tri(0, 0)] = t[0]; A[tri(1, 0)] = t[1]; A[tri(1, 1)] = t[2]; A[tri(2, 0)] = t[3]; A[tri(2, 1)] = t[4]; A[tri(2, 2)] = t[5];
@@ -218,14 +203,15 @@ __device__ void homog_normal_eq(const Pts &pts, int P, int lane, const double h[
 // [OCV-K LMSolverImpl::run] with maxIters = 10, eps = FLT_EPSILON on the 8 free entries
 template <class Pts>
 __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, double x[8]) {
-    double A[36], v[8], D[8], S;
-    homog_normal_eq(pts, P, lane, x, scratch, A, v, S);
+    // A trial point is evaluated with the normal-equations pass straight away (its residual sum and largest residual are
+    // what the gain ratio and the stop rule need); when the step is accepted -- the rule -- those normal equations are the
+    // next iteration's, and LMSolver's separate error-only evaluation is saved.  Same decisions, same points.
+    double A[36], v[8], D[8], S, rmax;
+    homog_normal_eq(pts, P, lane, x, scratch, A, v, S, rmax);
 #pragma unroll
     for (int a = 0; a < 8; a++) D[a] = A[tri(a, a)];
     const double Rlo = 0.25, Rhi = 0.75;
     double lambda = 1.0, lc = 0.75;
-    double rmax;
-    (void)homog_error(pts, P, lane, x, rmax);
     HSTAMP(6);
     for (int iter = 0;;) {
         HSTAMP(7);
@@ -241,8 +227,8 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, d
 #pragma unroll
         for (int a = 0; a < 8; a++) xd[a] = x[a] - d[a];
         HSTAMP(8);
-        double rdmax;
-        const double Sd = homog_error(pts, P, lane, xd, rdmax);
+        double Ac[36], vc[8], Sd, rdmax;
+        homog_normal_eq(pts, P, lane, xd, scratch, Ac, vc, Sd, rdmax);
         HSTAMP(9);
         double dS = 0.0, dv = 0.0, dmax = 0.0;          // dS = d . (2 v - A d)
 #pragma unroll
@@ -288,8 +274,10 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, d
         HSTAMP(10);
         if (Sd < S) {
 #pragma unroll
-            for (int a = 0; a < 8; a++) x[a] = xd[a];
-            homog_normal_eq(pts, P, lane, x, scratch, A, v, S);
+            for (int a = 0; a < 8; a++) { x[a] = xd[a]; v[a] = vc[a]; }
+#pragma unroll
+            for (int k = 0; k < 36; k++) A[k] = Ac[k];
+            S = Sd;
             rmax = rdmax;
         }
         HSTAMP(11);

@@ -75,8 +75,8 @@ with Solver(0) as s:
           "| sums over the lanes through LDS (wave_sums_lds)", v[14] - v[13])
     h = v[16:28]
     print("   homography: centroids + scales", h[1] - h[0], "| DLT sums", h[2] - h[1], "| 9x9 factor + inverse iteration", h[3] - h[2], "| compose", h[4] - h[3],
-          "| polish", h[5] - h[4], "= first normal equations + error", h[6] - h[4], "+ iterations; last iteration: 8x8 solve", h[8] - h[7],
-          "| error pass", h[9] - h[8], "| gain ratio + lambda", h[10] - h[9], "| normal equations", h[11] - h[10])
+          "| polish", h[5] - h[4], "= first normal equations", h[6] - h[4], "+ iterations; last iteration: 8x8 solve", h[8] - h[7],
+          "| normal equations at the trial point", h[9] - h[8], "| gain ratio + lambda", h[10] - h[9], "| acceptance", h[11] - h[10])
     print("   pose LM split: steps (6x6 solve + rotation)", v[8], "| passes at accepted points", v[9], "| passes at trial points", v[10])
 
     bb = (C.c_uint * (4096 * 4))()
