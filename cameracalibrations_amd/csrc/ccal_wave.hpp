@@ -135,8 +135,8 @@ __device__ __forceinline__ void tile_gram(const double *tile, int lane, int npts
 // computes 256 entries to deliver them and costs a tile store, 14 matrix instructions and a read-back per pass.
 // Transpose-reduce through LDS: lane l stores value j at [j][l] (rows padded to SUMS_LD doubles: consecutive lanes,
 // consecutive addresses on the way in; 16 rows' 16-byte reads on 64 distinct banks on the way out), then lane
-// (j, half) adds up one half of row j (NV <= 32; whole rows by lanes j < NV otherwise) with 16-byte reads, the partial
-// sums go back through LDS and every lane reads them all.  Fixed order of additions: the same bits on every run.
+// (j, half) adds up one half of row j (NV <= 32; whole rows by lanes j < NV otherwise) with 16-byte reads, the two halves
+// meet through v_permlane32_swap, the totals go back through LDS and every lane reads them all.  Fixed order of additions: the same bits on every run.
 // scratch: SUMS_LD * NV + 64 doubles, wave-private.
 // ---------------------------------------------------------------------------------------
 constexpr int SUMS_LD = 66;
@@ -163,10 +163,18 @@ __device__ __forceinline__ void wave_sums_lds(const double (&v)[NV], double *scr
             }
             part = a0 + a1;
         }
-        res[lane] = part;
+        // the two halves of a row meet in registers: v_permlane32_swap exchanges the upper 32 lanes of one operand with
+        // the lower 32 of the other, so with both operands the same value every lane ends up with lane j's + lane (32 + j)'s
+        {
+            const unsigned int lo = __double2loint(part), hi = __double2hiint(part);
+            const auto sl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+            const auto sh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+            part = __hiloint2double(sh[0], sl[0]) + __hiloint2double(sh[1], sl[1]);
+        }
+        if (lane < 32) res[lane] = part;
         wave_lds_sync();
 #pragma unroll
-        for (int j2 = 0; j2 < NV; j2++) out[j2] = res[j2] + res[32 + j2];
+        for (int j2 = 0; j2 < NV; j2++) out[j2] = res[j2];
     } else {
         double part = 0.0;
         if (lane < NV) {
