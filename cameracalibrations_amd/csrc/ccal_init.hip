@@ -718,7 +718,8 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
                 double num = 0.0, den = 0.0;
 #pragma unroll
                 for (int k = 0; k < 6; k++) { num += (rt[k] - prev[k]) * (rt[k] - prev[k]); den += prev[k] * prev[k]; }
-                if (++iters >= 20 || sqrt(num) / sqrt(den) < FLT_EPS) break;
+                // ||param - prevParam|| / ||prevParam|| < FLT_EPSILON, compared squared (no square roots, no division)
+                if (++iters >= 20 || num < FLT_EPS * FLT_EPS * den) break;
                 prevErrNorm = errNorm;
                 if (have_cand) {
                     // the accepted point's normal equations are already here: CALC_J's bookkeeping and the step at once
