@@ -116,6 +116,17 @@ struct NormPoints {              // A5: centred template xy -> normalised (undis
     }
 };
 
+// The correspondences of one image staged in LDS ([4][P]: Mx, My, mx, my), filled once per image: the homography makes
+// a dozen passes over the same points, and NormPoints::get (two divisions, five undistortion iterations) inlined at
+// every one of them made k_init_extrinsics 54 KB of code for a one-wave kernel that lives on instruction fetch.
+struct LdsPoints {
+    const double *s;
+    int P;
+    __device__ __forceinline__ void get(int p, double &Mx, double &My, double &mx, double &my) const {
+        Mx = s[p]; My = s[P + p]; mx = s[2 * P + p]; my = s[3 * P + p];
+    }
+};
+
 // A point source with this lane's first-pass point (index min(lane, P - 1): what every pass over the points asks for
 // first) kept in registers: one image is a dozen to several dozen passes over the same 54 points, and every pass
 // otherwise starts with a round trip to memory (and, for NormPoints, two divisions).  Same values, same results.
@@ -632,8 +643,16 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
     const unsigned long long t_begin = memtime_now();
 #endif
     ISTAMP(0);
-    CachedPoints<NormPoints> cpts;
-    cpts.init(pts, lane, P);
+    extern __shared__ __attribute__((aligned(16))) double s_pts[];   // [4][P]
+    for (int p = lane; p < P; p += 64) {
+        double Mx, My, mx, my;
+        pts.get(p, Mx, My, mx, my);
+        s_pts[p] = Mx; s_pts[P + p] = My; s_pts[2 * P + p] = mx; s_pts[3 * P + p] = my;
+    }
+    wave_lds_sync();
+    const LdsPoints lpts{s_pts, P};
+    CachedPoints<LdsPoints> cpts;
+    cpts.init(lpts, lane, P);
     const bool ok = wave_homography(cpts, P, lane, s_sums, H);
     ISTAMP(1);
     if (ok) {
@@ -810,7 +829,7 @@ hipError_t launch_init_focal_solve(hipStream_t stream, const double *foc_red, do
 }
 hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const float *img, const double *intr0,
                                   double *ext, int *fail_count, int N, int P) {
-    hipLaunchKernelGGL(k_init_extrinsics, dim3(N), dim3(64), 0, stream, obj, img, intr0, ext, fail_count, N, P);
+    hipLaunchKernelGGL(k_init_extrinsics, dim3(N), dim3(64), sizeof(double) * 4 * (size_t)P, stream, obj, img, intr0, ext, fail_count, N, P);
     return hipGetLastError();
 }
 
