@@ -160,6 +160,24 @@ __device__ __forceinline__ void homog_point(const double h[8], double Mx, double
     ev = yi - my;
 }
 
+// residual sum and largest |residual| at h (the trial evaluation of LMSolver; used here after a rejected step)
+template <class Pts>
+__device__ double homog_error(const Pts &pts, int P, int lane, const double h[8], double &rmax) {
+    double s = 0.0, m = 0.0;
+    for (int c0 = 0; c0 < P; c0 += 64) {
+        const int p = c0 + lane;
+        if (p < P) {
+            double Mx, My, mx, my, eu, ev, ww, xi, yi;
+            pts.get(p, Mx, My, mx, my);
+            homog_point(h, Mx, My, mx, my, eu, ev, ww, xi, yi);
+            s += eu * eu + ev * ev;
+            m = fmax(m, fmax(fabs(eu), fabs(ev)));
+        }
+    }
+    rmax = wave_max(m);
+    return wave_sum(s);
+}
+
 // A (8x8 packed lower) = J^T J, v = J^T r, S = r^T r at h.  The u-row of a correspondence touches only parameters
 // {0,1,2,6,7} and the v-row only {3,4,5,6,7}, and both carry the same first three entries (Mx w, My w, w): of the 45
 // entries 30 are distinct non-zero sums -- formed per lane, accumulated over the passes and summed over the lanes once
@@ -212,17 +230,22 @@ __device__ void homog_normal_eq(const Pts &pts, int P, int lane, const double h[
 }
 
 // [OCV-K LMSolverImpl::run] with maxIters = 10, eps = FLT_EPSILON on the 8 free entries
-template <class Pts>
+// SPEC = false: every trial by the error-only pass (LMSolver's own sequence): 44 fewer live doubles, which keeps
+// k_init_homography at two waves per SIMD where that matters (more images than SIMDs).
+template <bool SPEC, class Pts>
 __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, double x[8]) {
-    // A trial point is evaluated with the normal-equations pass straight away (its residual sum and largest residual are
-    // what the gain ratio and the stop rule need); when the step is accepted -- the rule -- those normal equations are the
-    // next iteration's, and LMSolver's separate error-only evaluation is saved.  Same decisions, same points.
+    // While steps are being accepted a trial point is evaluated with the normal-equations pass straight away (its residual
+    // sum and largest residual are what the gain ratio and the stop rule need): on acceptance those normal equations are the
+    // next iteration's, and LMSolver's separate error-only evaluation is saved.  After a rejected step -- near convergence
+    // they come in runs: the polish on pixel coordinates spends its last iterations there -- the trial goes back to the
+    // cheap error-only pass, and the normal equations follow only on acceptance.  Same decisions, same points.
     double A[36], v[8], D[8], S, rmax;
     homog_normal_eq(pts, P, lane, x, scratch, A, v, S, rmax);
 #pragma unroll
     for (int a = 0; a < 8; a++) D[a] = A[tri(a, a)];
     const double Rlo = 0.25, Rhi = 0.75;
     double lambda = 1.0, lc = 0.75;
+    bool last_accepted = SPEC;
     HSTAMP(6);
     for (int iter = 0;;) {
         HSTAMP(7);
@@ -239,7 +262,8 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, d
         for (int a = 0; a < 8; a++) xd[a] = x[a] - d[a];
         HSTAMP(8);
         double Ac[36], vc[8], Sd, rdmax;
-        homog_normal_eq(pts, P, lane, xd, scratch, Ac, vc, Sd, rdmax);
+        if (SPEC && last_accepted) homog_normal_eq(pts, P, lane, xd, scratch, Ac, vc, Sd, rdmax);
+        else Sd = homog_error(pts, P, lane, xd, rdmax);
         HSTAMP(9);
         double dS = 0.0, dv = 0.0, dmax = 0.0;          // dS = d . (2 v - A d)
 #pragma unroll
@@ -285,11 +309,21 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, d
         HSTAMP(10);
         if (Sd < S) {
 #pragma unroll
-            for (int a = 0; a < 8; a++) { x[a] = xd[a]; v[a] = vc[a]; }
+            for (int a = 0; a < 8; a++) x[a] = xd[a];
+            if (SPEC && last_accepted) {
 #pragma unroll
-            for (int k = 0; k < 36; k++) A[k] = Ac[k];
-            S = Sd;
+                for (int a = 0; a < 8; a++) v[a] = vc[a];
+#pragma unroll
+                for (int k = 0; k < 36; k++) A[k] = Ac[k];
+                S = Sd;
+            } else {
+                double r_unused;
+                homog_normal_eq(pts, P, lane, x, scratch, A, v, S, r_unused);
+            }
             rmax = rdmax;
+            last_accepted = SPEC;
+        } else {
+            last_accepted = false;
         }
         HSTAMP(11);
         iter++;
@@ -299,7 +333,7 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, d
 
 // [OCV-K findHomography(method 0)]: per-axis normalised DLT (smallest eigenvector of LtL by
 // shifted inverse iteration) + LM polish.  Every lane returns the same H.  false = degenerate.
-template <class Pts>
+template <bool SPEC, class Pts>
 __device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch, double H[9]) {
     HSTAMP(0);
     double cM0 = 0, cM1 = 0, cm0 = 0, cm1 = 0;
@@ -417,7 +451,7 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch
     for (int k = 0; k < 9; k++) H[k] *= s;
     HSTAMP(4);
     if (P > 4) {
-        homog_refine(pts, P, lane, scratch, H);
+        homog_refine<SPEC>(pts, P, lane, scratch, H);
         H[8] = 1.0;
     }
     HSTAMP(5);
@@ -430,6 +464,7 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch
 // ---------------------------------------------------------------------------------------
 // A4: homography per image + its two rows of the focal-length least squares
 // ---------------------------------------------------------------------------------------
+template <bool SPEC>
 __global__ __launch_bounds__(64) void k_init_homography(const float *__restrict__ obj, const float *__restrict__ img,
                                                          double *__restrict__ H_out, double *__restrict__ foc, int N,
                                                          int P, int width, int height) {
@@ -439,7 +474,7 @@ __global__ __launch_bounds__(64) void k_init_homography(const float *__restrict_
     CachedPoints<RawPoints> pts;
     pts.init(raw, lane, P);
     double H[9];
-    const bool ok = wave_homography(pts, P, lane, s_sums, H);
+    const bool ok = wave_homography<SPEC>(pts, P, lane, s_sums, H);
     if (lane < 9) H_out[(size_t)9 * i + lane] = ok ? H[lane] : 0.0;
     // [OCV-K cvInitIntrinsicParams2D]
     const double a2 = !width ? 0.5 : (width - 1) * 0.5, a5 = !height ? 0.5 : (height - 1) * 0.5;
@@ -572,6 +607,25 @@ __device__ __forceinline__ void rodrigues_inv(const double R[9], double r[3]) {
 // residual + Jacobian pass of the per-view LM
 struct FirstPoint { float m[3]; float2 uv; };      // this lane's point of the first pass (index min(lane, P - 1)), kept in registers
 
+// ||e||^2 of one view (error-only evaluation of a trial point: the lean form of the pose polish)
+__device__ double view_error(const float *obj, const float2 *img, int P, int lane, const double rt[6],
+                             const double R[9], const double in[NINTR], const FirstPoint &fp) {
+    double s = 0.0;
+    for (int c0 = 0; c0 < P; c0 += 64) {
+        const int p = c0 + lane;
+        if (p < P) {
+            const bool first = c0 == 0;
+            const double M[3] = {(double)(first ? fp.m[0] : obj[3 * p]), (double)(first ? fp.m[1] : obj[3 * p + 1]),
+                                 (double)(first ? fp.m[2] : obj[3 * p + 2])};
+            const float2 uv = first ? fp.uv : img[p];
+            double eu, ev;
+            point_residual(M, (double)uv.x, (double)uv.y, R, rt + 3, in, eu, ev);
+            s += eu * eu + ev * ev;
+        }
+    }
+    return wave_sum(s);
+}
+
 // JtJ (6x6 packed), Jt e and ||e||^2 of one view: 28 sums over the corners, formed per lane, accumulated over the
 // passes and summed over the lanes once (wave_sums_lds)
 constexpr int VSUMS = 28;
@@ -612,7 +666,11 @@ __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int
     return t[27];
 }
 
-__global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict__ obj, const float *__restrict__ img,
+// SPEC: trial points of the two polishes by their normal-equations passes (shortest chain per image: up to one image per
+// SIMD the launch is as long as its slowest image); !SPEC: CvLevMarq's / LMSolver's own error-only trial evaluations --
+// 98 fewer live doubles (what more images than SIMDs want: registers for a second wave per SIMD).
+template <bool SPEC>
+__global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const float *__restrict__ obj, const float *__restrict__ img,
                                                          const double *__restrict__ intr0, double *__restrict__ ext,
                                                          int *__restrict__ fail_count, int N, int P) {
     __shared__ __attribute__((aligned(16))) double s_sums[sums_scratch_doubles(HSUMS)];
@@ -653,7 +711,7 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
     const LdsPoints lpts{s_pts, P};
     CachedPoints<LdsPoints> cpts;
     cpts.init(lpts, lane, P);
-    const bool ok = wave_homography(cpts, P, lane, s_sums, H);
+    const bool ok = wave_homography<SPEC>(cpts, P, lane, s_sums, H);
     ISTAMP(1);
     if (ok) {
         double h1[3] = {H[0], H[3], H[6]}, h2[3] = {H[1], H[4], H[7]}, h3[3] = {H[2], H[5], H[8]};
@@ -740,7 +798,7 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
                 // ||param - prevParam|| / ||prevParam|| < FLT_EPSILON, compared squared (no square roots, no division)
                 if (++iters >= 20 || num < FLT_EPS * FLT_EPS * den) break;
                 prevErrNorm = errNorm;
-                if (have_cand) {
+                if (SPEC && have_cand) {
                     // the accepted point's normal equations are already here: CALC_J's bookkeeping and the step at once
 #pragma unroll
                     for (int k = 0; k < 21; k++) JtJ[k] = JtJ_c[k];
@@ -779,7 +837,8 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
         if (do_step) t_step += ts1 - ts0;
 #endif
         if (state == 2) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_sums, JtJ, JtErr, fp)); n_j++; }
-        else { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_sums, JtJ_c, JtErr_c, fp)); have_cand = true; n_e++; }
+        else if (SPEC) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_sums, JtJ_c, JtErr_c, fp)); have_cand = true; n_e++; }
+        else { errNorm = sqrt(view_error(obj, img_i, P, lane, rt, R, in, fp)); n_e++; }
 #ifdef CCAL_STAMPS
         const unsigned long long ts2 = memtime_now();
         if (state == 2) t_jac += ts2 - ts1; else t_err += ts2 - ts1;
@@ -806,8 +865,12 @@ __global__ __launch_bounds__(64) void k_init_extrinsics(const float *__restrict_
 // ---------------------------------------------------------------------------------------
 hipError_t launch_init_homography(hipStream_t stream, const float *obj, const float *img, double *H_out,
                                   double *foc_partials, int N, int P, int width, int height) {
-    hipLaunchKernelGGL(k_init_homography, dim3(N), dim3(64), 0, stream, obj, img, H_out, foc_partials, N, P, width,
-                       height);
+    // up to one image per SIMD the launch is as long as its slowest image: trial points by the normal-equations pass;
+    // beyond that it is throughput: the leaner form that keeps two waves per SIMD
+    if (N <= 1024)
+        hipLaunchKernelGGL(k_init_homography<true>, dim3(N), dim3(64), 0, stream, obj, img, H_out, foc_partials, N, P, width, height);
+    else
+        hipLaunchKernelGGL(k_init_homography<false>, dim3(N), dim3(64), 0, stream, obj, img, H_out, foc_partials, N, P, width, height);
     return hipGetLastError();
 }
 hipError_t launch_init_focal_reduce(hipStream_t stream, const double *foc_partials, double *foc_red, int N) {
@@ -829,7 +892,10 @@ hipError_t launch_init_focal_solve(hipStream_t stream, const double *foc_red, do
 }
 hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const float *img, const double *intr0,
                                   double *ext, int *fail_count, int N, int P) {
-    hipLaunchKernelGGL(k_init_extrinsics, dim3(N), dim3(64), sizeof(double) * 4 * (size_t)P, stream, obj, img, intr0, ext, fail_count, N, P);
+    if (N <= 1024)
+        hipLaunchKernelGGL(k_init_extrinsics<true>, dim3(N), dim3(64), sizeof(double) * 4 * (size_t)P, stream, obj, img, intr0, ext, fail_count, N, P);
+    else
+        hipLaunchKernelGGL(k_init_extrinsics<false>, dim3(N), dim3(64), sizeof(double) * 4 * (size_t)P, stream, obj, img, intr0, ext, fail_count, N, P);
     return hipGetLastError();
 }
 

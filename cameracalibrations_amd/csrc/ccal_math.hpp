@@ -267,6 +267,21 @@ CCAL_HD void point_rows_K(const double M[3], double u_obs, double v_obs, const d
     }
 }
 
+// Residual only (the error-only evaluation of a trial point in the pose polish's lean form).
+CCAL_HD void point_residual(const double M[3], double u_obs, double v_obs, const double R[9],
+                            const double t[3], const double in[NINTR], double &eu, double &ev) {
+    const double X = R[0] * M[0] + R[1] * M[1] + R[2] * M[2] + t[0];
+    const double Y = R[3] * M[0] + R[4] * M[1] + R[5] * M[2] + t[1];
+    const double Z = R[6] * M[0] + R[7] * M[1] + R[8] * M[2] + t[2];
+    const double z = (Z != 0.0) ? 1.0 / Z : 1.0;
+    const double x = X * z, y = Y * z;
+    const double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    const double a1 = 2.0 * x * y, a2 = r2 + 2.0 * x * x, a3 = r2 + 2.0 * y * y;
+    const double cd = 1.0 + in[4] * r2 + in[5] * r4 + in[8] * r6;
+    eu = in[0] * (x * cd + in[6] * a1 + in[7] * a2) + in[2] - u_obs;
+    ev = in[1] * (y * cd + in[6] * a3 + in[7] * a1) + in[3] - v_obs;
+}
+
 // ---------------------------------------------------------------------------------------
 // Small dense LA on fixed-size, fully unrolled arrays (wave-uniform values in VGPRs)
 // ---------------------------------------------------------------------------------------
