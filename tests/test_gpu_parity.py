@@ -456,12 +456,14 @@ def _two_rank_worker(rank, world, port, n_total, out, transport="torch"):
         with Solver(0, stream=torch.cuda.current_stream().cuda_stream) as s:
             s.set_problem(wl.obj, hi - lo, wl.image_size, aspect=wl.aspect, flags=wl.flags)
             s.set_image_points(torch.from_numpy(wl.img[lo:hi]).cuda())
-            if transport == "p2p":
-                s.init_p2p(world, rank, n_total, allgather_bytes_via_torch())
+            if transport == "p2p":                         # ranks sharing a GPU find out and take the one-workgroup exchange
+                assert s.init_p2p(world, rank, n_total, allgather_bytes_via_torch()) is True
+            elif transport == "p2p-fused":                 # the form real multi-GPU runs take: exchange fused into the prologue
+                assert s.init_p2p(world, rank, n_total, allgather_bytes_via_torch(), shared_device=False) is False
             else:
                 s.set_allreduce(TorchAllReduce(), world, rank, n_total)
             st, r = s.calibrate()
-            if transport == "p2p":                         # graph replay with the peers
+            if transport.startswith("p2p"):                # graph replay with the peers
                 st2, r2 = s.calibrate()
                 assert np.array_equal(r["intr"], r2["intr"]) and r["rms"] == r2["rms"]
             dist.barrier()                                 # no rank unmaps its inbox while a peer still sends
@@ -501,15 +503,18 @@ def test_sharded_fit_two_ranks_on_one_gpu():
     assert np.abs(rv - base["rvecs"]).max() < 1e-10 and np.abs(tv - base["tvecs"]).max() < 1e-9
 
 
-@pytest.mark.parametrize("world,n_total", [(2, 41), (3, 41), (2, 2650), (2, 4400)])
-def test_sharded_fit_p2p_exchange_on_one_gpu(world, n_total):
+@pytest.mark.parametrize("world,n_total,transport", [(2, 41, "p2p"), (3, 41, "p2p"), (2, 2650, "p2p"), (2, 4400, "p2p"),
+                                                     (2, 41, "p2p-fused"), (3, 41, "p2p-fused"), (4, 500, "p2p-fused")])
+def test_sharded_fit_p2p_exchange_on_one_gpu(world, n_total, transport):
     """Same joint fit through the direct exchange (ccal_p2p_export / ccal_p2p_connect): the ranks'
     inboxes are fine-grained device allocations mapped into each other's process through HIP IPC,
     rows travel as {epoch | payload} words written by the peers' kernels, every solve is one
     hipGraph per rank.  Ranks share the test box's single GPU (the fabric hop is the driver's
     multi-GPU run); 3 ranks cover uneven shards and the rank-ordered sum; 2650 images put more than
     320 workgroups on each rank, i.e. the separate exchange kernel instead of the fused prologue; 4400 images
-    (550 image groups per rank) exceed the resident grid, i.e. the looping sweep instantiation."""
+    (550 image groups per rank) exceed the resident grid, i.e. the looping sweep instantiation.  Ranks that share a GPU
+    switch themselves to the one-workgroup exchange ("p2p"); "p2p-fused" forces the form ranks with a GPU each take
+    (every workgroup of the trial kernel polls) on grids small enough to be resident together on the one GPU."""
     import socket
 
     import torch.multiprocessing as mp
@@ -521,7 +526,7 @@ def test_sharded_fit_p2p_exchange_on_one_gpu(world, n_total):
         port = sk.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_two_rank_worker, args=(world, port, n_total, out, "p2p"), nprocs=world, join=True)
+    mp.spawn(_two_rank_worker, args=(world, port, n_total, out, transport), nprocs=world, join=True)
     assert set(out.keys()) == set(range(world))
     a = out[0]
     for r in range(1, world):
@@ -711,6 +716,8 @@ def _c3_shard_worker(rank, world, port, out, transport, explicit_stream):
             s.set_image_points(torch.from_numpy(wl.img[lo:hi]).cuda())
             if transport == "p2p":
                 s.init_p2p(world, rank, wl.n_images, allgather_bytes_via_torch())
+            elif transport == "p2p-fused":
+                s.init_p2p(world, rank, wl.n_images, allgather_bytes_via_torch(), shared_device=False)
             else:
                 s.set_allreduce(TorchAllReduce(), world, rank, wl.n_images)
             st, r = s.calibrate()
@@ -723,7 +730,7 @@ def _c3_shard_worker(rank, world, port, out, transport, explicit_stream):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,transport", [(2, "p2p"), (4, "p2p"), (2, "torch-hook")])
+@pytest.mark.parametrize("world,transport", [(2, "p2p"), (4, "p2p"), (2, "p2p-fused"), (2, "torch-hook")])
 def test_c3_sharded_over_ranks_matches_oracle(world, transport):
     """BASELINE.json configs[3]: the SAME 1000-image x 9x6 set of configs[2], sharded per image over 2 / 4 ranks (sharing
     the test box's one GPU; at most 6 processes may use it, so 8 ranks are covered by the CPU world-size tests), through
@@ -739,7 +746,7 @@ def test_c3_sharded_over_ranks_matches_oracle(world, transport):
         port = sk.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_c3_shard_worker, args=(world, port, out, "p2p" if transport == "p2p" else "torch", False), nprocs=world, join=True)
+    mp.spawn(_c3_shard_worker, args=(world, port, out, transport if transport.startswith("p2p") else "torch", False), nprocs=world, join=True)
     assert set(out.keys()) == set(range(world))
     a = out[0]
     for r in range(1, world):
