@@ -63,3 +63,14 @@ double shim_sum(const double *xs, int n, int R, int *flags_out) {
     return acc_decode(part);
 }
 }
+
+// the two rows of [Je | Ji | e] of one corner (csrc/ccal_math.hpp): the kernels' factored form (point_rows_K) and the
+// plain form with the 3x9 Rodrigues Jacobian of SURVEY.md A.2 / A.3 (point_rows), for tests/test_acc_host.py
+extern "C" void shim_point_rows(const double *M, double u, double v, const double *rvec, const double *tvec, const double *intr,
+                                double aspect, double *rows_factored /* [2][16] */, double *rows_plain /* [2][16] */) {
+    double R[9], dR[27], R2[9], K[9];
+    rodrigues(rvec, R, dR);
+    rodrigues_RK(rvec, R2, K);
+    point_rows(M, u, v, R, dR, tvec, intr, aspect, rows_plain, rows_plain + 16);
+    point_rows_K(M, u, v, R2, K, tvec, intr, aspect, rows_factored, rows_factored + 16, 1.0);
+}

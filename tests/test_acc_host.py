@@ -26,6 +26,9 @@ def shim(tmp_path_factory):
     L.shim_gj_solve9.restype = C.c_int
     L.shim_gj_solve9.argtypes = [C.POINTER(C.c_double)] * 3
     L.shim_split.argtypes = [C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]
+    dp = C.POINTER(C.c_double)
+    L.shim_point_rows.restype = None
+    L.shim_point_rows.argtypes = [dp, C.c_double, C.c_double, dp, dp, dp, C.c_double, dp, dp]
     return L
 
 
@@ -174,3 +177,44 @@ def test_scaled_gauss_jordan_flags_indefinite_systems(shim):
     S = J.T @ J
     S[2, 2] = np.nan
     assert _gj(shim, S, np.ones(9))[0] == 0
+
+
+def test_factored_jacobian_rows_match_the_plain_form_and_the_oracle(shim):
+    """csrc/ccal_math.hpp:point_rows_K -- the kernels' rows with the twelve pose entries factored through one 2x2 distortion
+    Jacobian per corner (W = diag(fx, fy) Jd z [1 0 -x; 0 1 -y]; translation columns = W's columns; rotation columns
+    K[:,j] . ((R M) x W_r)) -- against (i) the plain form with the 3x9 Rodrigues Jacobian of SURVEY.md A.2 / A.3 built from
+    the same header, entry by entry, and (ii) the ORACLE's per-image Gram matrix assembled from these rows."""
+    from cameracalibrations_amd import synthetic as syn
+    from oracle import oracle as orc
+    dp = C.POINTER(C.c_double)
+
+    def rows(M, uv, r, t, intr, aspect):
+        a, b = np.zeros((2, 16)), np.zeros((2, 16))
+        arr = [np.ascontiguousarray(x, dtype=np.float64) for x in (M, r, t, intr)]
+        shim.shim_point_rows(arr[0].ctypes.data_as(dp), float(uv[0]), float(uv[1]), arr[1].ctypes.data_as(dp), arr[2].ctypes.data_as(dp),
+                             arr[3].ctypes.data_as(dp), float(aspect), a.ctypes.data_as(dp), b.ctypes.data_as(dp))
+        return a, b
+    rng = np.random.default_rng(12)
+    worst = 0.0
+    for trial in range(3000):
+        r = rng.uniform(-0.7, 0.7, 3) * (4.0 if trial % 50 == 0 else 1.0)          # now and then beyond one radian
+        t = np.r_[rng.uniform(-3, 3, 2), rng.uniform(8, 16)]
+        intr = np.r_[1610.0, 1600.0, 750.0, 1000.0, rng.uniform(-0.2, 0.2), rng.uniform(-0.05, 0.05), rng.uniform(-2e-3, 2e-3, 2),
+                     rng.uniform(-0.01, 0.01)]
+        M = np.r_[rng.uniform(0, 14), rng.uniform(0, 9), 0.0 if trial % 2 else rng.uniform(-1, 1)]
+        aspect = 1.2 if trial % 3 == 0 else 0.0
+        f, p = rows(M, (700.0, 900.0), r, t, intr, aspect)
+        scale = np.maximum(np.abs(p), 1e-3)
+        worst = max(worst, float((np.abs(f - p) / scale).max()))
+    assert worst < 1e-10, worst
+    # (ii) a whole image's Gram from the factored rows against the oracle's
+    wl = syn.named_workload("C2", n_images=3)
+    intr = wl.intr_true.copy()
+    for i in range(3):
+        G = np.zeros((16, 16))
+        for pnt in range(wl.n_points):
+            f, _ = rows(wl.obj[pnt].astype(np.float64), wl.img[i, pnt].astype(np.float64), wl.rvecs_true[i], wl.tvecs_true[i], intr, 0.0)
+            G += np.outer(f[0], f[0]) + np.outer(f[1], f[1])
+        Go = orc.image_gram(wl.obj, wl.img[i], wl.rvecs_true[i], wl.tvecs_true[i], intr, 0.0)
+        d = np.sqrt(np.abs(np.diag(Go))) + 1e-300
+        assert (np.abs(G - Go) / np.outer(d, d)).max() < 1e-11
