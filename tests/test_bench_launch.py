@@ -27,6 +27,15 @@ def test_bench_starts_its_own_ranks():
     assert d == {"dry_run": True, "n_gpus": 2, "sum_of_rank_numbers": 3, "launcher": "own child processes"}
 
 
+def test_bench_starts_eight_ranks():
+    """the driver's largest command, `python3 bench.py --gpus 8 ...`: eight child ranks rendezvous and one line comes back"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run"], capture_output=True,
+                       text=True, timeout=600, cwd=ROOT, env=_env())
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["sum_of_rank_numbers"] == 36 and json.loads(lines[0])["n_gpus"] == 8
+
+
 def test_bench_keeps_an_external_launcher():
     """With WORLD_SIZE in the environment (torch.distributed.run, the driver's N > 1 form) the process IS a rank."""
     env = dict(_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
