@@ -12,6 +12,8 @@ Extra blocks of the same JSON line (never `value`):
   "weak_scaling"  N > 1: every rank holds its own 1000 images of one joint fit (1000 N images).
   "c5"            BASELINE.json configs[4] shape, 10000 x 15x10 corners, full k1..k3,p1,p2 model: whole on the
                   one GPU at N = 1, sharded 10000 / N images per rank at N > 1 (1250 per rank at 8).
+  "transports"    N > 1: the headline's sharded fit once more over ncclAllReduce called by the library (RCCL) and over
+                  the torch.distributed hook, beside the direct row exchange the headline uses.
   "maps"          RowCol <-> XYZ maps and the four RMS error metrics on C3's 54 000 corners (N = 1).
   "detect"        corner detection (the step before the fit, reference src/detect_fit.jl:5-21) on the reference's six
                   example images and on two synthetic boards of its test generator (N = 1).
@@ -325,6 +327,34 @@ def dry_run(args):
     return 0
 
 
+class Deadline:
+    """`with Deadline(seconds, rank, line)`: if the body is still running after `seconds` (a transport stuck in a call that
+    never returns), rank 0 prints the line it has (`line()` -> dict) and the process ends with status 0; every rank holds
+    the same deadline and ends by itself.  Only for optional blocks after everything that counts has been measured."""
+
+    def __init__(self, seconds, rank, line):
+        self.seconds, self.rank, self.line, self.timer = seconds, rank, line, None
+
+    def _fire(self):
+        try:
+            if self.rank == 0:
+                print(json.dumps(self.line()), flush=True)
+            print(f"[bench] rank {self.rank}: optional block abandoned after {self.seconds:.0f} s", file=sys.stderr, flush=True)
+        finally:
+            os._exit(0)
+
+    def __enter__(self):
+        import threading
+        self.timer = threading.Timer(self.seconds, self._fire)
+        self.timer.daemon = True
+        self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.timer.cancel()
+        return False
+
+
 class Job:
     """One rank's side of the bench: process group, transports, timing helpers."""
 
@@ -392,11 +422,11 @@ class Job:
             self.dist.destroy_process_group()
 
     # ---- transports: every stage is decided by ALL ranks together (a rank never changes transport alone) ----
-    def attach_comm(self, sol, n_total):
+    def attach_comm(self, sol, n_total, want=None):
         from cameracalibrations_amd.distributed import TorchAllReduce, allgather_bytes_via_torch, broadcast_id_via_torch
         if self.world == 1:
             return "none"
-        world, rank, want = self.world, self.rank, self.args.allreduce
+        world, rank, want = self.world, self.rank, want or self.args.allreduce
         if want == "p2p":
             why = ""
             try:
@@ -452,7 +482,7 @@ class Job:
         return "torch.distributed all_reduce hook"
 
     # ---- one workload: solver set-up, timed solves, launch timing ----
-    def make_solver(self, wl, my_img, n_total, criteria):
+    def make_solver(self, wl, my_img, n_total, criteria, want=None):
         from cameracalibrations_amd.solver import Solver
 
         def local():
@@ -466,7 +496,7 @@ class Job:
             s.set_image_points(img_dev)
             return s, img_dev
         s, img_dev = self.together(local, "solver set-up")
-        comm = self.attach_comm(s, n_total)                    # (decides every stage with all ranks itself)
+        comm = self.attach_comm(s, n_total, want)              # (decides every stage with all ranks itself)
 
         def init():
             s.init_intrinsics()
@@ -798,6 +828,27 @@ def main():
         except BlockFailed as exc:    # (raised by every rank together)
             if rank == 0:
                 out["c5"] = {"error": str(exc)}
+    if extras and world > 1 and strong:
+        # The same sharded fit over the other two transports (the headline takes --allreduce, by default the direct row
+        # exchange): ncclAllReduce called by the library (RCCL; refuses ranks that share a device, so a rehearsal skips it)
+        # and the torch.distributed hook.  Last block, under a deadline: a transport that hangs costs this block only.
+        kinds = ["torch"] if args.share_gpu else ["rccl", "torch"]
+        tb = {}
+        with Deadline(240.0, rank, lambda: dict(out, transports=dict(tb, error="abandoned at its deadline")) if rank == 0 else None):
+            for kind in kinds:
+                if kind == args.allreduce:
+                    continue
+                try:
+                    st, _, comm_t = job.make_solver(wl, my_img, n_total, CRITERIA, want=kind)
+                    el, rk = job.timed_solves(st, steps_x, warm_x)
+                    tb[kind] = {"transport": comm_t, "ms_per_step": 1e3 * el / steps_x, "steps": steps_x,
+                                "rms_px": float(rk["rms"]), "iters": int(rk["iters"]), "sweeps_per_solve": int(rk["sweeps"])}
+                    st.close()
+                    del st
+                except BlockFailed as exc:    # (raised by every rank together)
+                    tb[kind] = {"error": str(exc)}
+        if rank == 0:
+            out["transports"] = tb
     if extras and world == 1:
         try:
             out["maps"] = maps_block(wl, rf, with_cpu=not args.no_cpu_baseline)

@@ -89,3 +89,7 @@ def test_bench_four_ranks_full_c3_rehearsal():
     assert c5["config"]["images_total"] == 2048 and c5["config"]["images_rank0"] == 512 and 0.12 < c5["lm"]["rms_px"] < 0.16
     for blk in (d, w, c5):
         assert blk["config"]["allreduce"].startswith("p2p") and "one exchange workgroup" in blk["config"]["allreduce"]
+    # the same sharded fit over the torch.distributed hook (RCCL inside the library refuses ranks that share a device)
+    t = d["transports"]
+    assert set(t) == {"torch"} and t["torch"]["transport"].startswith("torch.distributed")
+    assert abs(t["torch"]["rms_px"] - d["lm"]["rms_px"]) < 1e-9 and t["torch"]["iters"] == 4 and t["torch"]["ms_per_step"] > 0
