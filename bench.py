@@ -834,7 +834,7 @@ def main():
         # and the torch.distributed hook.  Last block, under a deadline: a transport that hangs costs this block only.
         kinds = ["torch"] if args.share_gpu else ["rccl", "torch"]
         tb = {}
-        with Deadline(240.0, rank, lambda: dict(out, transports=dict(tb, error="abandoned at its deadline")) if rank == 0 else None):
+        with Deadline(120.0, rank, lambda: dict(out, transports=dict(tb, error="abandoned at its deadline")) if rank == 0 else None):
             for kind in kinds:
                 if kind == args.allreduce:
                     continue
