@@ -88,6 +88,9 @@ struct ccal_ctx {
     int *h_flags = nullptr;
     // stage bookkeeping
     bool have_problem = false, have_img = false, have_intr = false, have_ext = false, have_result = false;
+    bool have_H = false;               // d_H holds k_init_homography's output for the current image points
+    bool intr_distorted = false;       // the initial intrinsics carry distortion (a caller's guess): no shortcut through d_H
+    int init_hmode = 2;                // how k_init_extrinsics obtains the normalised homography when d_H is valid (CCAL_INIT_HMODE)
     double intr0[CCAL_NINTR] = {0};
     ccal_stats stats{};
     // multi-GPU
@@ -184,6 +187,10 @@ int ccal_create(int device, ccal_ctx **out) {
     if (g && atoi(g) != 0) c->use_graph = false;
     const char *sp = getenv("CCAL_NO_SPIN");
     if (sp && atoi(sp) != 0) c->spin_wait = false;
+    if (const char *hm = getenv("CCAL_INIT_HMODE")) {       // experiments: 0 = OpenCV's own sequence (DLT + polish), 1, 2
+        const int v = atoi(hm);
+        if (v >= 0 && v <= 2) c->init_hmode = v;
+    }
     *out = c;
     return CCAL_OK;
 }
@@ -398,6 +405,7 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
     if (c->acc_R != old_R) c->acc_dirty = true;
     c->have_problem = true;
     c->have_img = c->have_intr = c->have_ext = c->have_result = false;
+    c->have_H = false;
     c->d_img = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
     return CCAL_OK;
@@ -419,6 +427,7 @@ int ccal_set_image_points(ccal_ctx *c, const float *img_host) {
     if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));
     c->d_img = c->d_img_own;
     c->have_img = true;
+    c->have_H = false;
     c->have_result = false;
     return CCAL_OK;
 }
@@ -436,6 +445,7 @@ int ccal_set_image_points_device(ccal_ctx *c, const float *img_device) {
                                     ", the context on device " + std::to_string(c->device));
     c->d_img = img_device;
     c->have_img = true;
+    c->have_H = false;                 // (the same pointer may hold other corners now)
     c->have_result = false;
     return CCAL_OK;
 }
@@ -447,6 +457,8 @@ int ccal_set_intrinsics(ccal_ctx *c, const double intr[CCAL_NINTR]) {
         if (!std::isfinite(intr[a])) return fail(CCAL_E_ARG, "ccal_set_intrinsics: non-finite value");
     if (!(intr[0] > 0 && intr[1] > 0)) return fail(CCAL_E_ARG, "ccal_set_intrinsics: focal lengths must be > 0");
     memcpy(c->intr0, intr, sizeof c->intr0);
+    c->intr_distorted = false;
+    for (int a = 4; a < CCAL_NINTR; a++) c->intr_distorted = c->intr_distorted || intr[a] != 0.0;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_intr0, c->intr0, sizeof c->intr0, hipMemcpyHostToDevice, c->stream));
     if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));
@@ -552,6 +564,13 @@ static int finish_init(ccal_ctx *c, bool intr, bool extr) {
     return finish_init_check(c, intr, extr);
 }
 
+// The initialisation kernels come in a latency form and a throughput form whose trial errors are summed differently; which
+// one runs is decided from the GLOBAL image count, so that every shard of a fit and the unsharded fit take the same one.
+static bool init_spec(const ccal_ctx *c) {
+    const int64_t ng = (sharded(c) && c->n_global > 0) ? c->n_global : c->N;
+    return ng <= (int64_t)init_simd_count();
+}
+
 // A4 in two halves, so that shards sharing one in-order stream (p2p_split) can put every shard's send in front
 // of every shard's receive:  a = homographies + local focal sums (+ send),  b = (receive | all-reduce) + 2x2 solve
 static int init_intrinsics_a(ccal_ctx *c) {
@@ -562,7 +581,8 @@ static int init_intrinsics_a(ccal_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     c->run_t0 = now_s();
     HIPCHK(launch_init_homography(c->stream, c->d_obj, c->d_img, c->d_H, c->d_foc_partials, c->N, c->P, c->width,
-                                  c->height));
+                                  c->height, init_spec(c)));
+    c->have_H = true;
     if (sharded(c)) {
         HIPCHK(launch_init_focal_reduce(c->stream, c->d_foc_partials, c->d_foc_red, c->N));
         if (via_p2p(c) && c->p2p_split) HIPCHK(launch_p2p_send(c->stream, c->p2p->dev(), c->d_foc_red, NFOC));
@@ -585,6 +605,7 @@ static int init_intrinsics_b(ccal_ctx *c) {
     }
     if (!c->defer_sync && (rc = finish_init(c, true, false)) != CCAL_OK) return rc;
     c->have_intr = true;
+    c->intr_distorted = false;         // cvInitIntrinsicParams2D leaves the distortion at zero
     c->have_result = false;
     c->stats.t_init_intr_s = now_s() - c->run_t0;
     return CCAL_OK;
@@ -603,7 +624,11 @@ int ccal_init_extrinsics(ccal_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     const double t0 = now_s();
     HIPCHK(hipMemsetAsync(c->d_fail, 0, sizeof(int), c->stream));     // word 0: failed poses (word 1: focal solve)
-    HIPCHK(launch_init_extrinsics(c->stream, c->d_obj, c->d_img, c->d_intr0, c->d_ext0, c->d_fail, c->N, c->P));
+    // the pixel-space homographies of the intrinsics stage stand in for the second, normalised homography OpenCV computes
+    // here whenever they exist for these corners and the intrinsics carry no distortion (k_init_extrinsics, HMODE)
+    const bool use_H = c->have_H && !c->intr_distorted && c->init_hmode != 0;
+    HIPCHK(launch_init_extrinsics(c->stream, c->d_obj, c->d_img, c->d_intr0, use_H ? c->d_H : nullptr, c->init_hmode, init_spec(c),
+                                  c->d_ext0, c->d_fail, c->N, c->P));
     int rc;
     if (!c->defer_sync && (rc = finish_init(c, false, true)) != CCAL_OK) return rc;
     c->stats.t_init_extr_s = now_s() - t0;

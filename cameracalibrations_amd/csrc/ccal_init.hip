@@ -571,14 +571,22 @@ __global__ __launch_bounds__(64) void k_init_focal_solve(const double *__restric
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ void polar3(double X[9]) {
     // orthogonal polar factor (== U V^T of the SVD) by Newton iteration X <- (X + X^-T) / 2
+    // (quadratic convergence: from the near-orthonormal matrices of a homography decomposition four or five steps reach
+    //  the fixed point; the loop stops once a step moves no entry by more than a few ulp)
     for (int it = 0; it < 10; it++) {
         const double c0 = X[4] * X[8] - X[5] * X[7], c1 = X[5] * X[6] - X[3] * X[8], c2 = X[3] * X[7] - X[4] * X[6];
         const double c3 = X[2] * X[7] - X[1] * X[8], c4 = X[0] * X[8] - X[2] * X[6], c5 = X[1] * X[6] - X[0] * X[7];
         const double c6 = X[1] * X[5] - X[2] * X[4], c7 = X[2] * X[3] - X[0] * X[5], c8 = X[0] * X[4] - X[1] * X[3];
         const double idet = 1.0 / (X[0] * c0 + X[1] * c1 + X[2] * c2);
         const double C[9] = {c0, c1, c2, c3, c4, c5, c6, c7, c8};   // cofactors: X^-T = C / det
+        double moved = 0.0;
 #pragma unroll
-        for (int k = 0; k < 9; k++) X[k] = 0.5 * (X[k] + C[k] * idet);
+        for (int k = 0; k < 9; k++) {
+            const double xn = 0.5 * (X[k] + C[k] * idet);
+            moved = fmax(moved, fabs(xn - X[k]));
+            X[k] = xn;
+        }
+        if (!(moved > 4.0e-16)) break;       // (also leaves on NaN)
     }
 }
 
@@ -669,9 +677,19 @@ __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int
 // SPEC: trial points of the two polishes by their normal-equations passes (shortest chain per image: up to one image per
 // SIMD the launch is as long as its slowest image); !SPEC: CvLevMarq's / LMSolver's own error-only trial evaluations --
 // 98 fewer live doubles (what more images than SIMDs want: registers for a second wave per SIMD).
-template <bool SPEC>
+// HMODE: where the normalised homography OpenCV computes before the polish comes from.
+//   0  [OCV-K] findHomography on the normalised points: DLT + LMSolver polish (the only form that works without a stored
+//      pixel-space homography, or with a distorted intrinsic guess)
+//   1  k_init_homography has just stored this image's polished PIXEL-space homography H_pix (board -> pixels); with zero
+//      distortion the board -> normalised-points homography is K^-1 H_pix T_c (T_c: the template's centring) up to the
+//      re-weighting of the residuals by (1/fx, 1/fy): the DLT is skipped and LMSolver's polish starts there
+//   2  ... and is skipped too: K^-1 H_pix T_c is decomposed directly, the 6-parameter pose polish that follows absorbs the
+//      difference (it converges to the pose optimum of the same reprojection error from either start)
+// LDSP = the normalised correspondences are staged in LDS (32 P bytes); false: read through NormPoints (any P).
+template <bool SPEC, int HMODE, bool LDSP>
 __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const float *__restrict__ obj, const float *__restrict__ img,
-                                                         const double *__restrict__ intr0, double *__restrict__ ext,
+                                                         const double *__restrict__ intr0, const double *__restrict__ H_pix,
+                                                         double *__restrict__ ext,
                                                          int *__restrict__ fail_count, int N, int P) {
     __shared__ __attribute__((aligned(16))) double s_sums[sums_scratch_doubles(HSUMS)];
     const int i = blockIdx.x, lane = threadIdx.x;
@@ -702,16 +720,61 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
 #endif
     ISTAMP(0);
     extern __shared__ __attribute__((aligned(16))) double s_pts[];   // [4][P]
-    for (int p = lane; p < P; p += 64) {
-        double Mx, My, mx, my;
-        pts.get(p, Mx, My, mx, my);
-        s_pts[p] = Mx; s_pts[P + p] = My; s_pts[2 * P + p] = mx; s_pts[3 * P + p] = my;
+    bool ok;
+    if constexpr (HMODE != 0) {
+        // H = K^-1 H_pix T_c, scaled to H[8] = 1 (every lane the same bits); a failed pixel-space homography was stored as zeros
+        double Hp[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Hp[k] = H_pix[(size_t)9 * i + k];
+        const double ifx = 1.0 / pts.in[0], ify = 1.0 / pts.in[1];
+        double G[9];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            G[j] = (Hp[j] - pts.in[2] * Hp[6 + j]) * ifx;
+            G[3 + j] = (Hp[3 + j] - pts.in[3] * Hp[6 + j]) * ify;
+            G[6 + j] = Hp[6 + j];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            H[a * 3] = G[a * 3];
+            H[a * 3 + 1] = G[a * 3 + 1];
+            H[a * 3 + 2] = G[a * 3] * pts.cMx + G[a * 3 + 1] * pts.cMy + G[a * 3 + 2];
+        }
+        ok = Hp[8] != 0.0 && fabs(H[8]) > DBL_EPS;
+        const double s = ok ? 1.0 / H[8] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) H[k] *= s;
     }
-    wave_lds_sync();
-    const LdsPoints lpts{s_pts, P};
-    CachedPoints<LdsPoints> cpts;
-    cpts.init(lpts, lane, P);
-    const bool ok = wave_homography<SPEC>(cpts, P, lane, s_sums, H);
+    if constexpr (HMODE != 2) {
+        auto run = [&](const auto &cpts) {
+            if constexpr (HMODE == 0) {
+                ok = wave_homography<SPEC>(cpts, P, lane, s_sums, H);
+            } else if (ok && P > 4) {
+                homog_refine<SPEC>(cpts, P, lane, s_sums, H);
+                H[8] = 1.0;
+            }
+        };
+        if constexpr (LDSP) {
+            for (int p = lane; p < P; p += 64) {
+                double Mx, My, mx, my;
+                pts.get(p, Mx, My, mx, my);
+                s_pts[p] = Mx; s_pts[P + p] = My; s_pts[2 * P + p] = mx; s_pts[3 * P + p] = my;
+            }
+            wave_lds_sync();
+            const LdsPoints lpts{s_pts, P};
+            CachedPoints<LdsPoints> cpts;
+            cpts.init(lpts, lane, P);
+            run(cpts);
+        } else {
+            CachedPoints<NormPoints> cpts;
+            cpts.init(pts, lane, P);
+            run(cpts);
+        }
+    }
+    if constexpr (HMODE != 0) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) ok = ok && (fabs(H[k]) < 1.0e300);
+    }
     ISTAMP(1);
     if (ok) {
         double h1[3] = {H[0], H[3], H[6]}, h2[3] = {H[1], H[4], H[7]}, h3[3] = {H[2], H[5], H[8]};
@@ -774,8 +837,12 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
     // Same decisions, same points; a rejected trial simply discards its normal equations.  Since the normal equations
     // became per-lane products + one LDS reduce the Jacobian pass is 2.7 k cycles; with round 2's 4.1 k this lost.
     // (tools/init_timing.py, one box: extrinsics stage 95.1 -> 87.5 us on C3, 530 -> 499 us on C5.)
+    // After a REJECTED step the re-damped trial points go back to CvLevMarq's own error-only evaluation, and the Jacobian
+    // follows on acceptance: a view whose third or fourth step lands on the optimum to rounding rejects the next one six to
+    // nine times in a row (lambda has to climb from 1e-6 past 1 before the step shrinks), and a launch of up to one image per
+    // SIMD is as long as its slowest image.
     double JtJ_c[21], JtErr_c[6];
-    bool have_cand = false;
+    bool have_cand = false, after_reject = false;
     for (int guard = 0; ok && guard < 20 * 24; guard++) {
         bool do_step = false;
         if (state == 1) {
@@ -790,7 +857,9 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
             if (errNorm > prevErrNorm && ++lambdaLg10 <= 16) {
                 do_step = true;
                 have_cand = false;
+                after_reject = true;
             } else {
+                after_reject = false;
                 lambdaLg10 = max(lambdaLg10 - 1, -16);
                 double num = 0.0, den = 0.0;
 #pragma unroll
@@ -837,7 +906,7 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
         if (do_step) t_step += ts1 - ts0;
 #endif
         if (state == 2) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_sums, JtJ, JtErr, fp)); n_j++; }
-        else if (SPEC) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_sums, JtJ_c, JtErr_c, fp)); have_cand = true; n_e++; }
+        else if (SPEC && !after_reject) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_sums, JtJ_c, JtErr_c, fp)); have_cand = true; n_e++; }
         else { errNorm = sqrt(view_error(obj, img_i, P, lane, rt, R, in, fp)); n_e++; }
 #ifdef CCAL_STAMPS
         const unsigned long long ts2 = memtime_now();
@@ -864,10 +933,10 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
 
 // ---------------------------------------------------------------------------------------
 hipError_t launch_init_homography(hipStream_t stream, const float *obj, const float *img, double *H_out,
-                                  double *foc_partials, int N, int P, int width, int height) {
+                                  double *foc_partials, int N, int P, int width, int height, bool spec) {
     // up to one image per SIMD the launch is as long as its slowest image: trial points by the normal-equations pass;
     // beyond that it is throughput: the leaner form that keeps two waves per SIMD
-    if (N <= 1024)
+    if (spec)
         hipLaunchKernelGGL(k_init_homography<true>, dim3(N), dim3(64), 0, stream, obj, img, H_out, foc_partials, N, P, width, height);
     else
         hipLaunchKernelGGL(k_init_homography<false>, dim3(N), dim3(64), 0, stream, obj, img, H_out, foc_partials, N, P, width, height);
@@ -890,12 +959,42 @@ hipError_t launch_init_focal_solve(hipStream_t stream, const double *foc_red, do
                        aspect);
     return hipGetLastError();
 }
-hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const float *img, const double *intr0,
-                                  double *ext, int *fail_count, int N, int P) {
-    if (N <= 1024)
-        hipLaunchKernelGGL(k_init_extrinsics<true>, dim3(N), dim3(64), sizeof(double) * 4 * (size_t)P, stream, obj, img, intr0, ext, fail_count, N, P);
-    else
-        hipLaunchKernelGGL(k_init_extrinsics<false>, dim3(N), dim3(64), sizeof(double) * 4 * (size_t)P, stream, obj, img, intr0, ext, fail_count, N, P);
+// One image per SIMD or fewer (decided by the caller from the GLOBAL image count, so that every shard of a fit and the
+// unsharded fit run the same arithmetic): the launch is as long as its slowest image -> speculative form; beyond that it is
+// throughput -> the lean form that keeps two waves per SIMD.
+int init_simd_count() {
+    static int cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (cached[dev] > 0) return cached[dev];
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    (void)hipGetLastError();
+    return cached[dev] = 4 * cus;
+}
+
+hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const float *img, const double *intr0, const double *H_pix,
+                                  int hmode, bool spec, double *ext, int *fail_count, int N, int P) {
+    // the staged correspondences (32 P bytes) next to the static scratch must fit a workgroup's 64 KB of LDS; bigger boards
+    // read them through NormPoints (lean form only: that instantiation exists for throughput anyway)
+    const size_t lds_pts = sizeof(double) * 4 * (size_t)P;
+    const bool ldsp = lds_pts + sizeof(double) * sums_scratch_doubles(HSUMS) + 256 <= 64 * 1024;
+    if (H_pix == nullptr) hmode = 0;
+    if (!ldsp) spec = false;
+    auto go = [&](auto kernel, size_t dyn) {
+        hipLaunchKernelGGL(kernel, dim3(N), dim3(64), dyn, stream, obj, img, intr0, H_pix, ext, fail_count, N, P);
+    };
+    if (hmode == 2) {                       // no pass over normalised points at all
+        if (spec) go(k_init_extrinsics<true, 2, true>, 0); else go(k_init_extrinsics<false, 2, true>, 0);
+    } else if (hmode == 1) {
+        if (!ldsp) go(k_init_extrinsics<false, 1, false>, 0);
+        else if (spec) go(k_init_extrinsics<true, 1, true>, lds_pts);
+        else go(k_init_extrinsics<false, 1, true>, lds_pts);
+    } else {
+        if (!ldsp) go(k_init_extrinsics<false, 0, false>, 0);
+        else if (spec) go(k_init_extrinsics<true, 0, true>, lds_pts);
+        else go(k_init_extrinsics<false, 0, true>, lds_pts);
+    }
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@ namespace ccal {
 
 // ccal_lm.hip
 int lm_sweep_blocks(int N);
+int lm_waves_per_image(int N, int P, bool fused);   // 1, 2 or 4: multi-pass boards are split over the waves of a workgroup while that fits the chip
 int lm_max_grid();               // workgroups of k_lm_trial resident on the current device (the sweep grid is capped there)
 struct TrialLaunch {              // one launch of k_lm_trial (see ccal_lm.hip)
     const float *obj = nullptr, *img = nullptr;
@@ -46,15 +47,17 @@ hipError_t launch_lm_recv(hipStream_t stream, const LmState *st, double *out, co
 
 // ccal_init.hip -- closed-form initialisation
 constexpr int NFOC = 8;   // doubles all-reduced for the focal least squares: AtA(3) Atb(2) fail(1) pad(2)
+int init_simd_count();          // SIMDs of the current device: up to one image per SIMD the init kernels run their speculative form
 hipError_t launch_init_homography(hipStream_t stream, const float *obj, const float *img, double *H_out,
-                                  double *foc_partials, int N, int P, int width, int height);
+                                  double *foc_partials, int N, int P, int width, int height, bool spec);
 hipError_t launch_init_focal_reduce(hipStream_t stream, const double *foc_partials, double *foc_red, int N);
 hipError_t launch_init_focal_reduce_solve(hipStream_t stream, const double *foc_partials, double *foc_red, int N, double *intr0,
                                           int *fail_count, int width, int height, double aspect);
 hipError_t launch_init_focal_solve(hipStream_t stream, const double *foc_red, double *intr0, int *fail_count,
                                    int width, int height, double aspect);
-hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const float *img, const double *intr0,
-                                  double *ext, int *fail_count, int N, int P);
+// H_pix: k_init_homography's output for the same image points (NULL: none); hmode 0 / 1 / 2 see k_init_extrinsics
+hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const float *img, const double *intr0, const double *H_pix,
+                                  int hmode, bool spec, double *ext, int *fail_count, int N, int P);
 
 // ccal_maps.hip -- RowCol <-> XYZ maps and the four RMS metrics
 struct MapIntr { double f[2], c[2], k, cs; };   // intrinsic map parameters + checker_size, a kernel argument by value

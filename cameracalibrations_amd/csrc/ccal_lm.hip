@@ -510,8 +510,17 @@ __device__ void lm_boot(LmState *ls, const LmInit &init, const double *intr0, in
 // is compiled separately because the loop's carried state costs it 75 VGPRs and a few hundred cycles.
 // KIND: 0 = first launch of a solve (builds S_0 instead of advancing), 1 = a later trial, 2 = the terminating
 // prologue-only launch.  Separate instantiations: each kind drops the other kinds' paths (and their registers).
-template <bool XCHG, bool LOOP, int KIND>
+// WPI = waves per image (1, 2 or 4; non-looping grids only).  A board of more than 64 corners takes several 64-corner passes,
+// and with one wave per image they are ONE wave's serial chain (rows -> tile -> Gram, three times over for 15 x 10 corners)
+// while, for a few hundred images, most of the chip's SIMDs hold no wave at all.  With WPI > 1 the image's corners are split
+// evenly over WPI waves of the workgroup -- each forms the rows and the 16 x 16 partial Gram of its share (the MFMA count
+// follows the share: 38 corners are 20 instructions, not 32) --, the partial Grams meet in LDS and are added in wave order,
+// and the image's first wave alone goes on to the 6 x 6 factor, the Schur contribution and the block.
+template <bool XCHG, bool LOOP, int KIND, int WPI = 1>
 __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(const TrialArgs A) {
+    static_assert(WPI == 1 || WPI == 2 || WPI == 4, "waves per image");
+    static_assert(WPI == 1 || (!LOOP && KIND != 2), "split images: one group per workgroup");
+    constexpr int IPW = WAVES / WPI;             // images per workgroup
     __shared__ __attribute__((aligned(16))) double s_wave[WAVES * TILE_D];
     __shared__ __attribute__((aligned(16))) double s_red[WAVES * NRED];
     __shared__ __attribute__((aligned(16))) double s_rs[NRED];
@@ -560,11 +569,17 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     // A workgroup sweeps the image groups g = blockIdx.x, blockIdx.x + gridDim.x, ... (four images each, one per
     // wave): the grid is capped at what the chip holds resident, so that the prologue above the loop -- state,
     // accumulators, LM advance -- runs once per resident workgroup, not once per four images.
-    const int n_groups = (N + WAVES - 1) / WAVES;
+    const int n_groups = (N + IPW - 1) / IPW;
     int g = blockIdx.x;
-    int img_i = g * WAVES + wave;
+    const int sub = WPI == 1 ? 0 : (wave & (WPI - 1));   // which share of the image's corners this wave takes
+    const bool leader = sub == 0;               // the wave that factors the image and writes its block
+    int img_i = g * IPW + (WPI == 1 ? wave : wave / WPI);
     bool active = img_i < N;                    // wave-uniform
     int ii = active ? img_i : N - 1;            // clamped: idle waves mirror the last image, store nothing
+    // corners [cbeg, cend) of the image are this wave's (even shares: a Gram step consumes two corners)
+    const int cpw = WPI == 1 ? P : ((((P + WPI - 1) / WPI) + 1) & ~1);
+    const int cbeg = WPI == 1 ? 0 : min(sub * cpw, P);
+    const int cend = WPI == 1 ? P : min(cbeg + cpw, P);
     const size_t acc_buf = (size_t)A.R * ACC_ROW;   // int64 words per accumulator buffer
 
     // ---- 0. loads that do not depend on the LM state are issued up front: the previous state, the
@@ -582,7 +597,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     // was a rejected candidate (rare) that is the accepted point's block, so it is requested before the state is known
     double ha = 0.0, hb = 0.0;
     const float2 *img2 = reinterpret_cast<const float2 *>(A.img) + (size_t)ii * P;
-    const int pc0 = lane < P ? lane : P - 1;
+    const int pc0 = min(cbeg + lane, max(cend - 1, 0));   // (an empty share reads corner 0 and uses nothing of it)
     float2 uv = make_float2(0.f, 0.f);
     float m0 = 0.f, m1 = 0.f, m2 = 0.f;
     if ((KIND != 2)) {
@@ -756,11 +771,11 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     rodrigues_RK(e6, R, K);
     STAMP(3);
     d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    for (int c0 = 0; c0 < P; c0 += 64) {
+    for (int c0 = cbeg; c0 < cend; c0 += 64) {
         const int p = c0 + lane;
-        const bool valid = p < P;
-        if (c0 > 0) {
-            const int pc = valid ? p : P - 1;
+        const bool valid = p < cend;
+        if (c0 > cbeg) {
+            const int pc = valid ? p : cend - 1;
             uv = img2[pc];
             m0 = A.obj[3 * pc]; m1 = A.obj[3 * pc + 1]; m2 = A.obj[3 * pc + 2];
         }
@@ -784,16 +799,30 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         tile_store_rows_masked(W, lane, mu, mv);
         wave_lds_sync();
         STAMP(5);
-        tile_gram(W, lane, min(64, P - c0), acc0, acc1);
+        tile_gram(W, lane, min(64, cend - c0), acc0, acc1);
         wave_lds_sync();                          // operands are in registers: the tile is free
 #endif
     }
     gram_to_lds(Gs, lane, acc0, acc1);
     STAMP(6);
+    if constexpr (WPI > 1) {
+        // the partial Grams of the image's waves meet here; its first wave adds them in wave order (fixed: same bits every run)
+        __syncthreads();
+        if (leader) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double t = Gs[lane + 64 * r];
+#pragma unroll
+                for (int j = 1; j < WPI; j++) t += Gs[j * TILE_D + lane + 64 * r];
+                Gs[lane + 64 * r] = t;
+            }
+        }
+    }
     wave_lds_sync();
 
 
-    if (A.gram_out != nullptr && active) {
+    const bool work = WPI == 1 || leader;        // (wave-uniform) this wave carries the image beyond its Gram
+    if (A.gram_out != nullptr && active && work) {
 #pragma unroll
         for (int r = 0; r < 4; r++) A.gram_out[(size_t)ii * 256 + lane + 64 * r] = Gs[lane + 64 * r];
     }
@@ -801,15 +830,17 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     // ---- 4. damped factor, U = C_l^-1 [B^T | h] and Y = L^-1 [B^T | h] at lam_next ----
     STAMP(7);
     double C[21], inv[6];
+    bool pd = false;
+    // lane j < 10 owns column j of [B^T | h]
+    const int yj = lane < 10 ? lane : 9;
+    double y[6];
+    if (work) {
 #pragma unroll
     for (int a = 0; a < 6; a++)
 #pragma unroll
         for (int b = 0; b <= a; b++) C[tri(a, b)] = Gs[a * 16 + b];   // LDS broadcast reads
     damp_diag<6>(C, lam_next);
-    const bool pd = chol_packed<6>(C, inv);
-    // lane j < 10 owns column j of [B^T | h]
-    const int yj = lane < 10 ? lane : 9;
-    double y[6];
+    pd = chol_packed<6>(C, inv);
     {
         const int col = yj < 9 ? 6 + yj : COL_E;
 #pragma unroll
@@ -859,6 +890,10 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
             red[64 + lane] = first_group ? ww : red[64 + lane] + ww;
         }
     }
+    } else {                                      // a helper wave of a split image: its share is in the leader's Gram
+        red[lane] = 0.0;
+        if (lane < 4) red[64 + lane] = 0.0;
+    }
     if (last_group) {
     STAMP(22);
     __syncthreads();
@@ -876,6 +911,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     STAMP(9);
 
     // ---- U = L^-T Y and this image's block for the next sweep's back-substitution ----
+    if (work) {
     bwd_subst<6>(C, inv, y);
     Hs[lane] = 0.0;                               // (the DS unit keeps one wave's writes in order)
     Hs[64 + lane] = 0.0;
@@ -897,6 +933,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         bo[lane] = Hs[lane];
         bo[64 + lane] = Hs[64 + lane];
 #endif
+    }
     }
     if (last_group) break;
     g = g_next;
@@ -1040,6 +1077,38 @@ hipError_t launch_acc_debug(hipStream_t stream, const double *vals, int n_rows, 
 // ---------------------------------------------------------------------------------------
 int lm_sweep_blocks(int N) { return (N + WAVES - 1) / WAVES; }
 
+// Waves per image of the sweep (k_lm_trial's WPI): boards of more than 64 corners are split over 4 or 2 waves as long as
+// the split grid still is at most ONE workgroup per compute unit: every wave repeats the image's pose and rotation, so
+// beyond that the extra waves cost the SIMDs they share more than the shorter chain returns (15 x 10 corners, launch
+// duration in a solve, wpi 1 / 2 / 4 -- 100 images: 10.6 / 9.4 / 8.2 us; 500: 11.0 / 10.3 / 11.4; 1000: 12.9 / 12.9 / 12.9:
+// profiles/r04_pass_parallel_probe.txt).  CCAL_WPI = 1 / 2 / 4 forces a value for experiments, CCAL_WPI_CAP the grid limit.
+int lm_waves_per_image(int N, int P, bool fused) {
+    if (P <= 64) return 1;
+    static int cus[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (cus[dev] <= 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        (void)hipGetLastError();
+        cus[dev] = n;
+    }
+    int cap = std::min(cus[dev], lm_max_grid());
+    (void)fused;                                  // (the fused exchange's 320-workgroup limit lies above the cap)
+    int want = 4;
+    if (const char *e = getenv("CCAL_WPI")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) want = v;
+    }
+    if (const char *e = getenv("CCAL_WPI_CAP")) {
+        const int v = atoi(e);
+        if (v > 0) cap = std::min(v, lm_max_grid());
+    }
+    for (int w = want; w > 1; w /= 2)
+        if (((long long)N * w + WAVES - 1) / WAVES <= cap) return w;
+    return 1;
+}
+
 // Workgroups of k_lm_trial the current device keeps resident (occupancy query x compute units; CCAL_MAX_GRID
 // overrides).  Both instantiations use the same resources up to a few SGPRs.
 int lm_max_grid() {
@@ -1069,8 +1138,10 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     a.xchg_fused = 0;
     memset(&a.p2p, 0, sizeof a.p2p);
     // sweep grid: one workgroup per four images up to what the chip keeps resident; beyond that the workgroups loop
-    const int grid = t.final_only ? 1 : std::min(lm_sweep_blocks(t.N), lm_max_grid());
-    const bool loop = !t.final_only && grid < lm_sweep_blocks(t.N);
+    const int wpi = t.final_only ? 1 : lm_waves_per_image(t.N, t.P, t.p2p != nullptr && t.xchg_fused);
+    const int groups = wpi == 1 ? lm_sweep_blocks(t.N) : (t.N * wpi + WAVES - 1) / WAVES;
+    const int grid = t.final_only ? 1 : std::min(groups, lm_max_grid());
+    const bool loop = !t.final_only && grid < groups;
     auto launch = [&](auto kernel) {
         if (t.ev_start != nullptr && t.ev_stop != nullptr)   // events bound to this dispatch: its own begin / end
             hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(WAVES * 64), 0, stream, t.ev_start, t.ev_stop, 0, a);
@@ -1080,6 +1151,8 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     auto pick = [&](auto xchg) {
         constexpr bool X = decltype(xchg)::value;
         if (t.final_only) launch(k_lm_trial<X, false, 2>);
+        else if (wpi == 4) { if (t.first) launch(k_lm_trial<X, false, 0, 4>); else launch(k_lm_trial<X, false, 1, 4>); }
+        else if (wpi == 2) { if (t.first) launch(k_lm_trial<X, false, 0, 2>); else launch(k_lm_trial<X, false, 1, 2>); }
         else if (t.first) { if (loop) launch(k_lm_trial<X, true, 0>); else launch(k_lm_trial<X, false, 0>); }
         else { if (loop) launch(k_lm_trial<X, true, 1>); else launch(k_lm_trial<X, false, 1>); }
     };
