@@ -34,6 +34,8 @@ namespace ccal { hipError_t debug_read_stamps(unsigned long long *out); hipError
 static constexpr int FUSED_XCHG_MAX_BLOCKS = 320;
 
 static constexpr size_t ACC_BYTES = sizeof(long long) * ACC_BUFS * ACC_MAX_REPLICAS * ACC_ROW;
+// the "workgroup done" counters of the tail-advance flow sit behind the accumulators: one memset zeroes both
+static constexpr size_t TAIL_BYTES = sizeof(unsigned int) * LM_TAIL_COUNTERS;
 
 static thread_local std::string g_err;
 
@@ -113,13 +115,15 @@ struct ccal_ctx {
     hipGraphExec_t g_first = nullptr;
     struct GraphKey {             // everything baked into the captured launches
         const void *obj, *img, *blk, *st, *acc, *red, *trace, *intr0, *ext0;
-        int N, P, batch, R;
+        int N, P, batch, R, tail;
         LmInit init;
     } graph_key{};
     bool defer_sync = false;      // one-shot path: stage syncs and checks are batched at the end
     double dbg_enqueue_s = 0, dbg_total_s = 0;
     int dbg_runs = 0;
     bool graph_dirty = true, use_graph = true, adaptive_batch = true, spin_wait = true;
+    bool tail_advance = false;    // experiment (-DCCAL_EXP_TAIL builds + CCAL_TAIL=1): the LM state machine advances at the tail of the
+                                  // sweep launch instead of the next launch's prologue (measured slower: profiles/r04_tail_advance_probe.txt)
     // a solve in flight (lm_begin .. lm_end)
     double run_t0 = 0;
     long run_max_trials = 0, run_trials = 0;
@@ -170,8 +174,9 @@ int ccal_create(int device, ccal_ctx **out) {
     HIPCHK(hipMalloc(&c->d_st, sizeof(LmState) * 2));          // S_k lives in d_st[k & 1]
     HIPCHK(hipMalloc(&c->d_st_scratch, sizeof(LmState) * 2));
     HIPCHK(hipMalloc(&c->d_red, sizeof(double) * NRED));
-    HIPCHK(hipMalloc(&c->d_acc, ACC_BYTES));
-    HIPCHK(hipMalloc(&c->d_acc_scratch, ACC_BYTES));
+    HIPCHK(hipMalloc(&c->d_acc, ACC_BYTES + TAIL_BYTES));
+    HIPCHK(hipMalloc(&c->d_acc_scratch, ACC_BYTES + TAIL_BYTES));
+    HIPCHK(hipMemset(c->d_acc_scratch, 0, ACC_BYTES + TAIL_BYTES));
     HIPCHK(hipMalloc(&c->d_foc_red, sizeof(double) * NFOC));
     HIPCHK(hipMalloc(&c->d_fail, sizeof(int) * 4));
     HIPCHK(hipMalloc(&c->d_intr0, sizeof(double) * 9));
@@ -187,6 +192,9 @@ int ccal_create(int device, ccal_ctx **out) {
     if (g && atoi(g) != 0) c->use_graph = false;
     const char *sp = getenv("CCAL_NO_SPIN");
     if (sp && atoi(sp) != 0) c->spin_wait = false;
+#ifdef CCAL_EXP_TAIL
+    if (const char *tl = getenv("CCAL_TAIL")) c->tail_advance = atoi(tl) != 0;
+#endif
     if (const char *hm = getenv("CCAL_INIT_HMODE")) {       // experiments: 0 = OpenCV's own sequence (DLT + polish), 1, 2
         const int v = atoi(hm);
         if (v >= 0 && v <= 2) c->init_hmode = v;
@@ -665,6 +673,10 @@ static int wait_progress(ccal_ctx *c, long target_trials) {
     return CCAL_OK;
 }
 
+static unsigned int *tail_counters(ccal_ctx *c) {
+    return reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(c->d_acc) + ACC_BYTES);
+}
+
 static TrialLaunch base_launch(ccal_ctx *c) {
     TrialLaunch t;
     t.obj = c->d_obj; t.img = c->d_img; t.blk = c->d_blk; t.st = c->d_st; t.acc = c->d_acc; t.R = c->acc_R;
@@ -674,12 +686,23 @@ static TrialLaunch base_launch(ccal_ctx *c) {
     return t;
 }
 
-// the exchange is fused into the trial's prologue unless the ranks of this fit run many workgroups each
+// the exchange is fused into the trial launch unless the ranks of this fit run many workgroups each (prologue form: every
+// workgroup polls; the tail-advance flow exchanges from ONE workgroup, whatever the grid)
 static bool xchg_fused(const ccal_ctx *c) {
     if (c->p2p_no_fuse) return false;  // other processes' ranks share this GPU: a waiting rank must hold one CU, not a grid
+    if (c->tail_advance) return true;
     const int64_t ng = c->n_global > 0 ? c->n_global : c->N;
     const int64_t per_rank = (ng + c->world - 1) / (c->world > 0 ? c->world : 1);
     return lm_sweep_blocks((int)per_rank) <= FUSED_XCHG_MAX_BLOCKS;
+}
+
+// Does this context's solve advance the state machine at the tail of the sweep launches?  Only where the sums of a trial
+// are complete inside the launch: one GPU, or the fused xGMI exchange; a row summed BETWEEN two launches (RCCL, the host
+// hook, k_lm_exchange, the split send / receive of shards sharing a stream) is consumed by the next launch's prologue.
+static bool uses_tail(const ccal_ctx *c) {
+    if (!c->tail_advance) return false;
+    if (via_p2p(c)) return !c->p2p_split && xchg_fused(c);
+    return !sharded(c);
 }
 
 // Launch trial k (k_lm_trial): its prologue consumes the exact accumulators of trial k - 1 -- directly
@@ -691,7 +714,12 @@ static int enqueue_trial(ccal_ctx *c, hipStream_t stream, int k, bool final_only
     t.first = k == 0;
     t.final_only = final_only ? 1 : 0;
     if (via_p2p(c)) t.p2p = &c->p2p->dev();
-    if (k > 0) {
+    if (uses_tail(c)) {
+        if (final_only) return CCAL_OK;       // the tail of the last sweep has already advanced and reported
+        t.tail = 1;
+        t.tail_cnt = tail_counters(c);
+        if (via_p2p(c)) t.xchg_fused = 1;
+    } else if (k > 0) {
         if (via_p2p(c)) {
             if (c->p2p_split) {
                 // this shard's row was sent by enqueue_send(k), like every other shard's of this stream: collect them
@@ -716,7 +744,7 @@ static int enqueue_trial(ccal_ctx *c, hipStream_t stream, int k, bool final_only
         t.ev_start = c->ev[2 * c->ev_used];
         t.ev_stop = c->ev[2 * c->ev_used + 1];
         c->ev_used++;
-    } else if (final_only && c->time_sweeps) {      // (the last terminating launch of a solve is the one that counts)
+    } else if (final_only && c->time_sweeps) {      // (the last terminating launch of a solve is the one that counts; prologue flows only)
         t.ev_start = c->ev[2 * MAX_KINDS];
         t.ev_stop = c->ev[2 * MAX_KINDS + 1];
         c->ev_final_used = true;
@@ -772,7 +800,7 @@ static int lm_prepare(ccal_ctx *c) {
     if (c->acc_dirty) {
         // first solve of a problem, or the last one did not end with its terminating launch (which leaves
         // the accumulators cleared): start from zeros
-        HIPCHK(hipMemsetAsync(c->d_acc, 0, ACC_BYTES, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_acc, 0, ACC_BYTES + TAIL_BYTES, c->stream));
     }
     c->acc_dirty = true;               // until this solve is seen to have ended with its terminating launch
     c->run_graphed = false;
@@ -790,7 +818,7 @@ static int lm_begin(ccal_ctx *c) {
         memset(&key, 0, sizeof key);
         key.obj = c->d_obj; key.img = c->d_img; key.blk = c->d_blk; key.st = c->d_st; key.acc = c->d_acc; key.R = c->acc_R;
         key.red = c->d_red; key.trace = c->d_trace; key.intr0 = c->d_intr0; key.ext0 = c->d_ext0;
-        key.N = c->N; key.P = c->P; key.batch = c->lm_batch; key.init = make_init(c);
+        key.N = c->N; key.P = c->P; key.batch = c->lm_batch; key.init = make_init(c); key.tail = uses_tail(c) ? 1 : 0;
         if (c->graph_dirty || !c->g_first || memcmp(&key, &c->graph_key, sizeof key) != 0) {
             const int rc = capture_graph(c, &c->g_first);
             if (rc) return rc;
@@ -879,6 +907,10 @@ static int lm_end(ccal_ctx *c) {
     if (c->adaptive_batch && r.trials != c->lm_batch) {
         c->lm_batch = r.trials < 1 ? 1 : (r.trials > 48 ? 48 : r.trials);
         c->graph_dirty = true;
+    }
+    if (r.status == -6) {
+        c->acc_dirty = true;           // accumulators / counters are in an unknown state: zero them before the next solve
+        return fail(CCAL_E_DEVICE, "ccal_lm_run: a sweep workgroup never reported its sums (tail-advance wait expired)");
     }
     if (r.status == -4) return fail(CCAL_E_NONFINITE, "ccal_lm_run: non-finite reprojection error on the device");
     if (r.status == -3) return fail(CCAL_E_DEGENERATE, "ccal_lm_run: reduced intrinsic system not positive definite");
@@ -1519,6 +1551,10 @@ int ccal_time_sweep(ccal_ctx *c, int32_t reps, double *avg_us) {
     t.st = c->d_st_scratch; t.trace = nullptr; t.host_result = nullptr; t.host_progress = nullptr;
     t.acc = c->d_acc_scratch;
     t.first = 1; t.k = 0;
+    if (c->tail_advance) {             // the flow a single-GPU solve runs: the mean then includes workgroup 0's tail
+        t.tail = 1;
+        t.tail_cnt = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(c->d_acc_scratch) + ACC_BYTES);
+    }
     if (c->have_result) {
         const LmState *fin = c->d_st + (c->h_st->trials & 1);
         t.intr0 = reinterpret_cast<const double *>(reinterpret_cast<const char *>(fin) + offsetof(LmState, intr_prev));

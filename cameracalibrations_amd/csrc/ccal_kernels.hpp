@@ -29,8 +29,12 @@ struct TrialLaunch {              // one launch of k_lm_trial (see ccal_lm.hip)
     int N = 0, P = 0, k = 0, first = 0, final_only = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // optional: timestamps of this dispatch
     const P2PDev *p2p = nullptr;  // image-sharded fit: launch the exchanging instantiation
-    int xchg_fused = 0;           // ... whose prologue runs the row exchange itself
+    int xchg_fused = 0;           // ... whose prologue (or, tail flow, workgroup 0's tail) runs the row exchange itself
+    int tail = 0;                 // tail-advance flow: workgroup 0 advances the state machine at the END of this launch (no
+                                  // row_in, no terminating launch); every launch of a solve must then use it
+    unsigned int *tail_cnt = nullptr;   // [LM_TAIL_COUNTERS] zeroed words in device memory (zero again after every launch)
 };
+constexpr int LM_TAIL_COUNTERS = 64;
 hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t);
 int lm_acc_replicas(int nblocks);
 // diagnostics: n_rows rows of 68 doubles added like n_rows workgroups would, read back like a prologue does -> out[68]

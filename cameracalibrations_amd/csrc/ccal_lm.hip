@@ -376,6 +376,7 @@ __device__ __forceinline__ void acc_read_issue(const long long *__restrict__ acc
 // Replica sums -> LDS.  The replicas are added as 64-bit integers (a limb holds 52 payload bits and an address
 // receives at most grid / R adds, the grid is capped at 1024 workgroups: the sum over all replicas stays below
 // 2^62), then split ONCE into the two exactly representable halves acc_decode() takes.
+template <bool SC1 = false>
 __device__ __forceinline__ void acc_read_stage(const long long *__restrict__ acc, int R, AccPart *s_acc, int tid, const AccRegs &q) {
     if (tid >= ACC_PAIRS) return;
     long long t0 = 0, t1 = 0;
@@ -385,7 +386,14 @@ __device__ __forceinline__ void acc_read_stage(const long long *__restrict__ acc
     for (int r0 = 8; r0 < R; r0 += 8) {             // more than eight replicas (very large grids only)
         longlong2 v[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) v[r] = (r0 + r < R) ? src[(size_t)(r0 + r) * ACC_PAIRS] : make_longlong2(0, 0);
+        for (int r = 0; r < 8; r++) {
+            if (r0 + r >= R) v[r] = make_longlong2(0, 0);
+            else if (SC1) {
+                const long long *w = acc + (size_t)(r0 + r) * ACC_ROW + 2 * tid;
+                v[r].x = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v[r].y = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else v[r] = src[(size_t)(r0 + r) * ACC_PAIRS];
+        }
 #pragma unroll
         for (int r = 0; r < 8; r++) { t0 += v[r].x; t1 += v[r].y; }
     }
@@ -414,24 +422,67 @@ __device__ __forceinline__ double acc_row_decode(const AccPart *s_acc, int col) 
     return v;
 }
 
-// this workgroup's 68 sums -> limbs -> integer atomics into one replica (threads 0..67)
-__device__ __forceinline__ void acc_add(long long *__restrict__ dst, int col, double v) {
+// this workgroup's 68 sums -> limbs -> integer atomics into one replica (threads 0..67).
+// Returns a value that depends on what the atomics FETCHED: a caller that consumes it (acc_wait) has thereby waited until
+// its adds were performed at the memory side -- what the tail-advance flow needs before it reports the workgroup done.
+__device__ __forceinline__ long long acc_add(long long *__restrict__ dst, int col, double v) {
     int j, flag;
     int64_t lo, hi;
+    long long seen = 0;
     acc_split(v, j, lo, hi, flag);
 #ifdef CCAL_EXP_NO_ACC             // timing experiment only (no sums at all)
-    if (col >= 0) return;
+    if (col >= 0) return 0;
 #endif
 #ifdef CCAL_EXP_STORE_NOT_ATOMIC   // timing experiment only (wrong sums): what the atomics cost against plain stores
     dst[j * NRED + col] = lo;
     dst[(j + 1) * NRED + col] = hi;
-    return;
+    return 0;
 #endif
     if (flag) {
-        __hip_atomic_fetch_add(dst + (flag - 1) * NRED + ACC_FLAG_COL, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seen ^= __hip_atomic_fetch_add(dst + (flag - 1) * NRED + ACC_FLAG_COL, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-        if (lo != 0) __hip_atomic_fetch_add(dst + j * NRED + col, (long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (hi != 0) __hip_atomic_fetch_add(dst + (j + 1) * NRED + col, (long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lo != 0) seen ^= __hip_atomic_fetch_add(dst + j * NRED + col, (long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hi != 0) seen ^= __hip_atomic_fetch_add(dst + (j + 1) * NRED + col, (long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return seen;
+}
+
+// consume what acc_add fetched: the compiler has to keep the atomics in their returning form and wait for them here
+__device__ __forceinline__ void acc_wait(long long seen) {
+    asm volatile("" ::"v"((int)seen), "v"((int)(seen >> 32)) : "memory");
+}
+
+// ---- tail-advance flow: "all workgroups of this launch have added their sums" ---------------------------------------
+// Every workgroup, once its own adds have been performed (acc_wait + barrier), adds 1 to one of TAIL_CNT counters
+// (workgroup index mod TAIL_CNT: a few adds per address, no pile-up on one word); workgroup 0 -- the one that advances the
+// state machine at the tail of the launch -- polls their sum.  It only ever waits at the very end of its own work, for
+// workgroups of the same launch that are resident or will be as soon as a slot frees; the wait is bounded all the same.
+constexpr int TAIL_CNT = LM_TAIL_COUNTERS;
+constexpr long long TAIL_BUDGET_TICKS = 300000000ll;   // 3 s on the 100 MHz wall clock
+
+__device__ __forceinline__ bool tail_wait_all(unsigned int *cnt, int lane, unsigned int want) {
+    const long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned int mine = __hip_atomic_load(cnt + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double tot = wave_sum((double)mine);       // (small integers: exact)
+        if (tot >= (double)want) return true;
+        if (wall_clock64() - t0 > TAIL_BUDGET_TICKS) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// the accumulators of a finished launch, read past the caches (they were formed by memory-side atomics of all XCDs): thread
+// t < ACC_PAIRS takes pair t of every replica
+__device__ __forceinline__ void acc_read_issue_sc1(const long long *__restrict__ acc, int R, int tid, AccRegs &q) {
+    const long long *src = acc + 2 * (tid < ACC_PAIRS ? tid : 0);
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        if (tid < ACC_PAIRS && r < R) {
+            q.v[r].x = __hip_atomic_load(src + (size_t)r * ACC_ROW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            q.v[r].y = __hip_atomic_load(src + (size_t)r * ACC_ROW + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            q.v[r] = make_longlong2(0, 0);
+        }
     }
 }
 
@@ -463,7 +514,8 @@ struct TrialArgs {
     int first;                    // k == 0: build S_0 instead of advancing
     int final_only;               // prologue only (detect termination, report to the host)
     int xchg_fused;               // image-sharded fit: the prologue exchanges the local row with the peer GPUs
-    P2PDev p2p;                   // used by the XCHG instantiation only
+    unsigned int *tail_cnt;       // [TAIL_CNT] "workgroup done" counters of the tail-advance flows (zero between launches)
+    P2PDev p2p;                   // used by the exchanging instantiations only
 };
 
 // S_0: the state OpenCV's loop starts from
@@ -516,16 +568,31 @@ __device__ void lm_boot(LmState *ls, const LmInit &init, const double *intr0, in
 // evenly over WPI waves of the workgroup -- each forms the rows and the 16 x 16 partial Gram of its share (the MFMA count
 // follows the share: 38 corners are 20 instructions, not 32) --, the partial Grams meet in LDS and are added in wave order,
 // and the image's first wave alone goes on to the 6 x 6 factor, the Schur contribution and the block.
-template <bool XCHG, bool LOOP, int KIND, int WPI = 1>
+// FLOW: where the LM state machine is advanced.
+//   FLOW_PRO / FLOW_PRO_XCHG  in the PROLOGUE of the next launch, by every workgroup redundantly (from the accumulators,
+//                  from an all-reduced row, or -- XCHG -- after the fused row exchange); a solve of T trials is T + 1 launches.
+//   FLOW_TAIL / FLOW_TAIL_XCHG  at the TAIL of the launch that produced the sums, ONCE: every workgroup reports when its adds
+//                  have been performed, workgroup 0 waits for all reports at the end of its own sweep, reads the totals,
+//                  (XCHG: exchanges the row with the peer GPUs -- one workgroup polls, not a grid,) runs lm_advance_wave
+//                  and stores S_{k+1}; the next launch's prologue is one 0.9 KB load of that state instead of 22 KB of
+//                  accumulators + decode + a 3.9 k-cycle advance in every workgroup, and the solve needs no terminating
+//                  launch: the tail that sees `done` reports to the host itself.  Nothing else waits inside a launch.
+enum : int { FLOW_PRO = 0, FLOW_PRO_XCHG = 1, FLOW_TAIL = 2, FLOW_TAIL_XCHG = 3 };
+template <int FLOW, bool LOOP, int KIND, int WPI = 1>
 __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(const TrialArgs A) {
+    constexpr bool XCHG = FLOW == FLOW_PRO_XCHG;
+    constexpr bool TAIL = FLOW >= FLOW_TAIL;
     static_assert(WPI == 1 || WPI == 2 || WPI == 4, "waves per image");
     static_assert(WPI == 1 || (!LOOP && KIND != 2), "split images: one group per workgroup");
+    static_assert(!(TAIL && KIND == 2), "the tail-advance flows have no terminating launch");
     constexpr int IPW = WAVES / WPI;             // images per workgroup
     __shared__ __attribute__((aligned(16))) double s_wave[WAVES * TILE_D];
     __shared__ __attribute__((aligned(16))) double s_red[WAVES * NRED];
     __shared__ __attribute__((aligned(16))) double s_rs[NRED];
     __shared__ __attribute__((aligned(16))) double s_S[9 * SROW];
     __shared__ LmState ls;
+    __shared__ unsigned int s_seq;
+    __shared__ int s_tail_ok;
     double *s_all = s_wave;       // XCHG: the peers' rows are staged in the (not yet used) tile space
     AccPart *s_acc = reinterpret_cast<AccPart *>(s_wave + P2P_MAX_RANKS * NRED);   // staged accumulator sums, likewise
     static_assert(P2P_MAX_RANKS * NRED + 2 * ACC_ROW <= WAVES * TILE_D, "prologue staging exceeds the tile space");
@@ -585,13 +652,16 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     // ---- 0. loads that do not depend on the LM state are issued up front: the previous state, the
     //         accumulators of the previous trial, both parities of the block head (rvec,tvec | U | pd)
     //         -- or the start pose -- and the first 64 corners ----
-    const LmState *prev = A.st + ((A.k - 1) & 1);
+    // (tail-advance flows: S_k was stored into st[k & 1] by the tail of launch k - 1; otherwise S_{k-1} sits in st[(k - 1) & 1])
+    const LmState *prev = A.st + ((TAIL ? A.k : A.k - 1) & 1);
     double sw = 0.0, row_v = 0.0;
     AccRegs q;
     if ((KIND != 0)) {
         if (tid < STATE_WORDS) sw = reinterpret_cast<const double *>(prev)[tid];
-        if (A.row_in != nullptr) { if (tid < NRED) row_v = A.row_in[tid]; }
-        else acc_read_issue(A.acc + (size_t)((A.k + 2) % 3) * acc_buf, A.R, tid, q);
+        if constexpr (!TAIL) {
+            if (A.row_in != nullptr) { if (tid < NRED) row_v = A.row_in[tid]; }
+            else acc_read_issue(A.acc + (size_t)((A.k + 2) % 3) * acc_buf, A.R, tid, q);
+        }
     }
     // block words lane (ha) and 64 + lane (hb) of this image.  Trial k - 1 wrote buffer (k - 1) & 1; unless its point
     // was a rejected candidate (rare) that is the accepted point's block, so it is requested before the state is known
@@ -610,8 +680,9 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         }
         uv = img2[pc0];                         // coalesced 8 B per lane
         m0 = A.obj[3 * pc0]; m1 = A.obj[3 * pc0 + 1]; m2 = A.obj[3 * pc0 + 2];
-        // the buffer the NEXT trial adds into was last read one launch ago: clear it now
-        if (blockIdx.x == 0) acc_clear(A.acc + (size_t)((A.k + 1) % 3) * acc_buf, A.R, 1, tid);
+        // the buffer the NEXT trial adds into was last read one launch ago: clear it now (tail flows: the tail that reads a
+        // buffer clears it, every buffer is zero between launches)
+        if (!TAIL && blockIdx.x == 0) acc_clear(A.acc + (size_t)((A.k + 1) % 3) * acc_buf, A.R, 1, tid);
     }
     int oa, ob;                                 // (a, b) of the packed S0 entry this lane assembles
     tri_decode(lane < 45 ? lane : 0, oa, ob);
@@ -631,12 +702,36 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     // ---- 1. the state of this trial, S_k, in LDS (every workgroup computes the same bits) ----
     unsigned int seq = 0;
     if constexpr (XCHG) seq = __hip_atomic_load(A.p2p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (FLOW == FLOW_TAIL_XCHG) {
+        // only workgroup 0 exchanges (at its tail); one thread reads -- and, first launch of a solve, advances -- the sequence number
+        if (blockIdx.x == 0 && tid == 0) {
+            unsigned int e = __hip_atomic_load(A.p2p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (KIND == 0) {
+                e += 1u;
+                __hip_atomic_store(A.p2p.epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_seq = e;                          // (read after the barriers of the sweep)
+        }
+    }
     if ((KIND == 0)) {
         lm_boot(&ls, A.init, A.intr0, tid);
         // no other workgroup of this launch reads the sequence number; the launches after it see seq + 1
         if constexpr (XCHG)
             if (blockIdx.x == 0 && tid == 0)
                 __hip_atomic_store(A.p2p.epoch, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if constexpr (TAIL) {
+        if (tid < STATE_WORDS) reinterpret_cast<double *>(&ls)[tid] = sw;
+        __syncthreads();
+        STAMP(11);
+        STAMP(12);
+        if (ls.done) {
+            // solve already terminated: surplus launch; the terminal state is carried along for the launches after it
+            if (blockIdx.x == 0) {
+                LmState *nxt = A.st + ((A.k + 1) & 1);
+                if (tid < STATE_WORDS) reinterpret_cast<double *>(nxt)[tid] = reinterpret_cast<const double *>(&ls)[tid];
+            }
+            return;
+        }
     } else {
         if (tid < STATE_WORDS) reinterpret_cast<double *>(&ls)[tid] = sw;
         if (A.row_in != nullptr) {
@@ -687,7 +782,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     }
     STAMP(1);
     WG_TIME(1);
-    if (blockIdx.x == 0) {
+    if (!TAIL && blockIdx.x == 0) {
         LmState *cur = A.st + (A.k & 1);
         if (tid < STATE_WORDS) reinterpret_cast<double *>(cur)[tid] = reinterpret_cast<const double *>(&ls)[tid];
         if (A.host_progress != nullptr && tid < 64) {
@@ -734,6 +829,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
                                 __builtin_amdgcn_readlane(__double2loint(v), src));
     };
 
+    long long seen = 0;                           // what this thread's accumulator adds fetched (tail flows wait for it)
     for (bool first_group = true;; first_group = false) {
     const int g_next = g + (int)gridDim.x;
     const bool last_group = !LOOP || g_next >= n_groups;   // workgroup-uniform
@@ -905,7 +1001,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         // ... and exact, order-independent across workgroups: limbs added with integer atomics
         // (replica = workgroup index mod R: with R = 8 and round-robin dispatch that is the workgroup's XCD, so one
         //  replica is only ever added to through one L2 -- choosing it from HW_REG_XCC_ID instead measured the same)
-        acc_add(A.acc + ((size_t)(A.k % 3) * A.R + (blockIdx.x & (A.R - 1))) * ACC_ROW, tid, s);
+        seen = acc_add(A.acc + ((size_t)(A.k % 3) * A.R + (blockIdx.x & (A.R - 1))) * ACC_ROW, tid, s);
     }
     }
     STAMP(9);
@@ -955,6 +1051,62 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     wave_lds_sync();                              // the block has left LDS: the next group's tile may overwrite it
     }
     STAMP(10);
+    if constexpr (TAIL) {
+        // ---- 5. tail: this workgroup's adds have been performed -> report; workgroup 0 advances the state machine ONCE ----
+        acc_wait(seen);
+        __syncthreads();                          // every adding thread of the workgroup has its fetched values back
+        if (tid == 0)
+            __hip_atomic_fetch_add(A.tail_cnt + (blockIdx.x & (TAIL_CNT - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blockIdx.x != 0) return;
+        if (wave == 0) {
+            const bool all_in = tail_wait_all(A.tail_cnt, lane, gridDim.x);
+            __hip_atomic_store(A.tail_cnt + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
+            if (lane == 0) s_tail_ok = all_in ? 1 : 0;
+        }
+        __syncthreads();
+        const long long *acc_k = A.acc + (size_t)(A.k % 3) * acc_buf;
+        AccRegs qt;
+        acc_read_issue_sc1(acc_k, A.R, tid, qt);
+        acc_read_stage<true>(acc_k, A.R, s_acc, tid, qt);
+        __syncthreads();
+        // the totals are in LDS: the buffer is zero again before the launch ends (plain stores: the next adds come after the
+        // kernel boundary, nothing reads it before)
+        acc_clear(A.acc + (size_t)(A.k % 3) * acc_buf, A.R, 1, tid);
+        if (tid < NRED) {
+            double v = acc_row_decode(s_acc, tid);
+            if (!s_tail_ok && tid == RED_ERR) v = __longlong_as_double(0x7ff8000000000000ll);   // a workgroup never reported: abort the solve
+            s_rs[tid] = v;
+            if (tid < RED_DA) { s_S[oa * SROW + ob] = v; s_S[ob * SROW + oa] = v; }   // (tid == lane of wave 0)
+        }
+        __syncthreads();
+        if constexpr (FLOW == FLOW_TAIL_XCHG) {
+            // the whole all-reduce of the image-sharded fit, by this one workgroup: row -> the peers' inboxes, their rows added in rank order
+            const unsigned int sq = s_seq;
+            p2p_exchange_rows(A.p2p, p2p_tag(sq, (unsigned)(A.k + 1)), p2p_slot(sq, (unsigned)(A.k + 1)), s_rs, s_all, NRED, tid, true);
+            if (tid < RED_DA) {
+                const double v = s_rs[tid];
+                s_S[oa * SROW + ob] = v;
+                s_S[ob * SROW + oa] = v;
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            lm_advance_wave<true, false>(&ls, s_rs, s_S, A.trace, lane, A.k + 1);
+            if (!s_tail_ok) { ls.status = -6; ls.done = 1; }    // (host: CCAL_E_DEVICE, accumulators and counters re-zeroed)
+        }
+        __syncthreads();
+        LmState *nxt = A.st + ((A.k + 1) & 1);
+        if (tid < STATE_WORDS) reinterpret_cast<double *>(nxt)[tid] = reinterpret_cast<const double *>(&ls)[tid];
+        if (A.host_progress != nullptr && tid < 64) {
+            if (ls.done != 0 && A.host_result != nullptr && tid < HOST_WORDS)
+                reinterpret_cast<double *>(A.host_result)[tid] = reinterpret_cast<const double *>(&ls)[tid];
+            if (tid == 0) {
+                const unsigned long long word = ((unsigned long long)(unsigned)ls.trials << 32) | (ls.done ? 1ull : 0ull);
+                if (ls.done) __hip_atomic_store(A.host_progress, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                else __hip_atomic_store(A.host_progress, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
     STAMP_RT(31);
     WG_TIME(2);
 }
@@ -1121,7 +1273,7 @@ int lm_max_grid() {
         const int v = atoi(e);
         if (v > 0) return cached[dev] = std::min(v, 1024);
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lm_trial<true, true, 1>, WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lm_trial<FLOW_PRO_XCHG, true, 1>, WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     (void)hipGetLastError();
     return cached[dev] = std::min(per_cu * cus, 1024);   // (1024: the accumulator replicas are summed in int64)
@@ -1136,7 +1288,15 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     a.init = t.init; a.gram_out = t.gram_out; a.N = t.N; a.P = t.P; a.k = t.k; a.first = t.first;
     a.final_only = t.final_only;
     a.xchg_fused = 0;
+    a.tail_cnt = t.tail_cnt;
     memset(&a.p2p, 0, sizeof a.p2p);
+    const bool tail = t.tail != 0;
+    if (tail && (t.final_only || t.row_in != nullptr || t.tail_cnt == nullptr)) return hipErrorInvalidValue;
+#ifndef CCAL_EXP_TAIL
+    // The tail-advance flows are an experiment (profiles/r04_tail_advance_probe.txt: +3.7 us per launch on C3 against the
+    // prologue form; built by tools/variants.py tail=CCAL_EXP_TAIL): the shipped library does not carry their kernels.
+    if (tail) return hipErrorInvalidValue;
+#endif
     // sweep grid: one workgroup per four images up to what the chip keeps resident; beyond that the workgroups loop
     const int wpi = t.final_only ? 1 : lm_waves_per_image(t.N, t.P, t.p2p != nullptr && t.xchg_fused);
     const int groups = wpi == 1 ? lm_sweep_blocks(t.N) : (t.N * wpi + WAVES - 1) / WAVES;
@@ -1148,9 +1308,10 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
         else
             hipLaunchKernelGGL(kernel, dim3(grid), dim3(WAVES * 64), 0, stream, a);
     };
-    auto pick = [&](auto xchg) {
-        constexpr bool X = decltype(xchg)::value;
-        if (t.final_only) launch(k_lm_trial<X, false, 2>);
+    auto pick = [&](auto flow) {
+        constexpr int X = decltype(flow)::value;
+        if constexpr (X < FLOW_TAIL) { if (t.final_only) { launch(k_lm_trial<X, false, 2>); return; } }
+        if (t.final_only) return;
         else if (wpi == 4) { if (t.first) launch(k_lm_trial<X, false, 0, 4>); else launch(k_lm_trial<X, false, 1, 4>); }
         else if (wpi == 2) { if (t.first) launch(k_lm_trial<X, false, 0, 2>); else launch(k_lm_trial<X, false, 1, 2>); }
         else if (t.first) { if (loop) launch(k_lm_trial<X, true, 0>); else launch(k_lm_trial<X, false, 0>); }
@@ -1159,9 +1320,18 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     if (t.p2p != nullptr) {
         a.p2p = *t.p2p;
         a.xchg_fused = t.xchg_fused;
-        pick(std::true_type());
+#ifdef CCAL_EXP_TAIL
+        if (tail && t.xchg_fused) pick(std::integral_constant<int, FLOW_TAIL_XCHG>());
+        else if (tail) return hipErrorInvalidValue;   // (an exchanging fit without the fused exchange goes through row_in)
+        else
+#endif
+        pick(std::integral_constant<int, FLOW_PRO_XCHG>());
+#ifdef CCAL_EXP_TAIL
+    } else if (tail) {
+        pick(std::integral_constant<int, FLOW_TAIL>());
+#endif
     } else {
-        pick(std::false_type());
+        pick(std::integral_constant<int, FLOW_PRO>());
     }
     return hipGetLastError();
 }
