@@ -36,6 +36,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6    # FP64 vector (= FP64 matrix) peak: 256 CUs x 128 flop/clk x 2.4 GHz
+# the clock these launches actually hold (s_memtime / s_memrealtime stamps, tools/stamps.py): 2.32 GHz with one wave per SIMD
+# (C3, profiles/r03_wave_stamps.json), 2.1 GHz under sustained FP64 load (C5, profiles/r03_c5_pmc_utilisation_summary.json)
+CLOCK_GHZ_LATENCY, CLOCK_GHZ_FP64_LOAD, CLOCK_GHZ_PEAK = 2.32, 2.1, 2.4
 KERNEL_BOUNDARY_US = 1.45  # dependent kernel boundary, same stream (guide, "boundary" row of the price list)
 METRIC = "corner-residuals/sec + LM iters-to-tol, 1000 imgs x 9x6 corners, 1/2/4/8 GPU"
 
@@ -327,10 +330,14 @@ def dry_run(args):
     return 0
 
 
+DEADLINE_EXIT = 3      # exit status of a run whose optional last block hung (the JSON line has been printed)
+
+
 class Deadline:
     """`with Deadline(seconds, rank, line)`: if the body is still running after `seconds` (a transport stuck in a call that
-    never returns), rank 0 prints the line it has (`line()` -> dict) and the process ends with status 0; every rank holds
-    the same deadline and ends by itself.  Only for optional blocks after everything that counts has been measured."""
+    never returns), rank 0 prints the line it has (`line()` -> dict, marked `"incomplete": true`) and the process ends with
+    status DEADLINE_EXIT (non-zero: the measured line is out, but a hung transport is a finding, not a clean run); every rank
+    holds the same deadline and ends by itself.  Only for optional blocks after everything that counts has been measured."""
 
     def __init__(self, seconds, rank, line):
         self.seconds, self.rank, self.line, self.timer = seconds, rank, line, None
@@ -338,10 +345,10 @@ class Deadline:
     def _fire(self):
         try:
             if self.rank == 0:
-                print(json.dumps(self.line()), flush=True)
+                print(json.dumps(dict(self.line(), incomplete=True)), flush=True)
             print(f"[bench] rank {self.rank}: optional block abandoned after {self.seconds:.0f} s", file=sys.stderr, flush=True)
         finally:
-            os._exit(0)
+            os._exit(DEADLINE_EXIT)
 
     def __enter__(self):
         import threading
@@ -556,13 +563,13 @@ def shard(wl, world, rank):
 # Latency floor of ONE LM trial, from quantities the kernel does not choose (measured constants: the guide's price list
 # and profiles/r02_latency_probe.txt, tools/lat_probe.hip): what any one-launch-per-trial design pays when every image
 # has a SIMD to itself (the C3 regime).  Not this kernel's own instruction stream: the kernel sits well above it.
-CLOCK_GHZ = 2.3                 # measured in-kernel clock of these launches (profiles/r02_wave_stamps.json)
-LAT = {"fma": 4.2, "rcp": 16.2, "rsq": 16.2, "dpp": 12.2, "readlane": 28.2, "lds_round_trip": 128.0,   # cycles
+CLOCK_GHZ = CLOCK_GHZ_LATENCY   # measured in-kernel clock of the one-wave-per-SIMD launches
+LAT = {"fma": 4.2, "rcp": 16.2, "rsq": 16.2, "dpp": 12.2, "readlane": 28.2, "lds_round_trip": 128.0,   # cycles (profiles/r04_latency_probe.txt)
        "global_state": 740.0, "global_atomics": 480.0}      # dependent global round trips at kernel start / end
 LATENCY_FLOOR_SOURCE = (
     "boundary: dependent kernel boundary, guide price list; global: the two true dependent global round trips of a trial "
     "(previous state + accumulators in, 740 cycles; the memory-side atomics out, 480 cycles; DESIGN.md section 4); chain: the "
-    "minimum dependent FP64 chain of one image's trial at the measured per-step latencies of profiles/r02_latency_probe.txt "
+    "minimum dependent FP64 chain of one image's trial at the measured per-step latencies of profiles/r04_latency_probe.txt "
     "(v_fma_f64 4.2, v_rcp/v_rsq_f64 16.2, v_mov_b64_dpp 12.2, readlane + use 28.2 cycles; LDS write -> read 128) -- limbs -> "
     "doubles 10 fma; 9 Gauss-Jordan pivots x (dpp + rcp + 3 fma) + quotient; state hand-off 2 LDS round trips; pose 1 mul + "
     "4 dpp adds + readlane + 1 add; rotation series 3 + 11 + 4 fma; projection + Jacobian row 3 + 1 + rcp + 4 + 18 fma; "
@@ -611,8 +618,8 @@ def roofline_block(N_rank, P, K, sweep_us, n_timed, b2b_us, events_ms_per_step, 
            "fp64_frac": tflops / FP64_PEAK_TFLOPS}
     # traffic: HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/pmc.sh:
     # FETCH_SIZE and WRITE_SIZE in separate passes, both calibrated on a known byte count with this access width)
-    for shape, names in (((1000, 54), ("r03_pmc_traffic_summary.json", "r02_pmc_traffic_summary.json")),
-                         ((10000, 150), ("r03_c5_pmc_traffic_summary.json",))):
+    for shape, names in (((1000, 54), ("r04_pmc_traffic_summary.json", "r03_pmc_traffic_summary.json", "r02_pmc_traffic_summary.json")),
+                         ((10000, 150), ("r04_c5_pmc_traffic_summary.json", "r03_c5_pmc_traffic_summary.json"))):
         for name in names:
             pmc = committed_profile(name)
             if pmc and (N_rank, P) == shape and "ccal::k_lm_trial" in pmc and out["traffic"] is None:
@@ -622,6 +629,15 @@ def roofline_block(N_rank, P, K, sweep_us, n_timed, b2b_us, events_ms_per_step, 
     if N_rank > 1024:      # more images than SIMDs: a launch is FP64 throughput, not one image's latency chain
         terms = {"boundary": KERNEL_BOUNDARY_US, "fp64_flop_at_vector_peak": flops / (FP64_PEAK_TFLOPS * 1e6)}
         floor_us = sum(terms.values())
+        # the chip does not hold 2.4 GHz under this load: the same floor at the clock it holds, and what that makes of the launch
+        held = FP64_PEAK_TFLOPS * CLOCK_GHZ_FP64_LOAD / CLOCK_GHZ_PEAK
+        out["fp64_peak_tflops_at_held_clock"] = held
+        out["fp64_frac_at_held_clock"] = tflops / held
+        out["held_clock_ghz"] = CLOCK_GHZ_FP64_LOAD
+        out["latency_floor_us_at_held_clock"] = KERNEL_BOUNDARY_US + flops / (held * 1e6)
+        out["frac_of_floor_at_held_clock"] = out["latency_floor_us_at_held_clock"] / sweep_us if sweep_us > 0 else None
+    else:
+        out["held_clock_ghz"] = CLOCK_GHZ_LATENCY
     out["latency_floor_us"] = floor_us
     out["frac_of_floor"] = floor_us / sweep_us if sweep_us > 0 else None
     out["latency_floor_terms_us"] = terms
@@ -825,6 +841,21 @@ def main():
                                                                                                  "true" if my5.shape[0] > 2048 else "false"))}
             s5.close()
             del s5
+            if world == 1 and args.c5_images is None:
+                # the per-GPU share of configs[4] at 8 GPUs (rank 0's 1250 images x 150 corners) on this one GPU, resident: what
+                # an 8-GPU run can at best make of a trial at kernel level, reportable while no 8-GPU node is measured
+                my8 = shard(wl5, 8, 0)
+                s8, _, _ = job.make_solver(wl5, my8, my8.shape[0], CRITERIA)
+                el8, r8 = job.timed_solves(s8, st5, 3)
+                us8, n8, b2b8, _ = job.launch_timing(s8, min(st5, 10))
+                out["c5"]["share_at_8"] = {
+                    "images": int(my8.shape[0]), "corners_per_image": wl5.n_points, "avg_launch_us": us8, "launches_timed": n8,
+                    "avg_launch_us_back_to_back": b2b8, "ms_per_step": 1e3 * el8 / st5, "sweeps_per_solve": int(r8["sweeps"]),
+                    "whole_avg_launch_us": us5, "predicted_kernel_speedup": us5 / us8 if us8 > 0 else None,
+                    "what": "k_lm_trial on rank 0's 1250-image shard as its own fit on one GPU (no exchange): whole / share bounds the "
+                            "8-GPU scaling of a trial before any exchange cost; north_star asks >= 6x"}
+                s8.close()
+                del s8
         except BlockFailed as exc:    # (raised by every rank together)
             if rank == 0:
                 out["c5"] = {"error": str(exc)}

@@ -71,6 +71,9 @@ SIGNATURES = {
     "ccal_p2p_connect": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "ccal_p2p_selftest": (C.c_int, [C.c_void_p, C.c_int32]),
     "ccal_p2p_set_exchange": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ccal_p2p_export2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p]),
+    "ccal_p2p_connect2": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "ccal_p2p_shared_device": (C.c_int, [C.c_void_p]),
     "ccal_device_uuid": (C.c_int, [C.c_int32, C.c_char_p]),
     "ccal_set_problem": (C.c_int, [C.c_void_p, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double,
                                    C.c_uint32, C.c_int32, C.c_double]),
@@ -106,6 +109,8 @@ SIGNATURES = {
                                       C.c_int32, _dp, C.POINTER(C.c_int32), _dp]),
     "ccal_debug_image_grams": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "ccal_debug_acc_sum": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32, _dp]),
+    "ccal_debug_p2p_world": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, _dp, _dp]),
+    "ccal_debug_multi_set_epoch": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.c_uint32]),
     "ccal_get_init": (C.c_int, [C.c_void_p, _dp, _dp]),
     "ccal_time_sweep": (C.c_int, [C.c_void_p, C.c_int32, _dp]),
 }

@@ -102,6 +102,8 @@ struct ccal_ctx {
     Comm *comm = nullptr;              // native RCCL communicator (ccal_comm_init_rank)
     P2P *p2p = nullptr;                // direct xGMI row exchange (ccal_p2p_export / ccal_p2p_connect)
     bool p2p_no_fuse = false;          // ranks of several processes share this GPU: one-workgroup exchange, never whole grids polling
+    bool p2p_shared_detected = false;  // ccal_p2p_connect2 found two ranks with the same device uuid
+    int p2p_mode = 0;                  // ccal_p2p_set_exchange: 0 automatic, 1 one-workgroup exchange, 2 fused whatever was detected
     bool p2p_split = false;            // shards of one host thread share this GPU AND its stream: send / receive as two kernels
     Detector *detector = nullptr;      // corner detector buffers (ccal_detect_corners)
     int64_t n_global = 0;
@@ -286,6 +288,8 @@ int ccal_p2p_export(ccal_ctx *c, int32_t world_size, int32_t rank, char handle_o
     HIPCHK(hipStreamSynchronize(c->stream));
     delete c->p2p;
     c->graph_dirty = true;             // a captured solve may hold the old inbox pointers
+    c->p2p_shared_detected = false;
+    c->p2p_no_fuse = c->p2p_mode == 1;
     c->p2p = new P2P();
     std::string err;
     if (c->p2p->create(world_size, rank, handle_out, err) != 0) {
@@ -316,6 +320,39 @@ int ccal_p2p_connect(ccal_ctx *c, const char *handles, int64_t n_images_global) 
     c->n_global = n_images_global;
     return CCAL_OK;
 }
+
+// The same pair with the rank's device id travelling inside the blob (64-byte inbox handle + 16-byte device uuid): the
+// library sees for itself when two ranks share a GPU and takes the one-workgroup exchange then (a waiting rank must hold one
+// compute unit, not a grid that keeps the sender off the chip) -- callers no longer have to gather the ids and call
+// ccal_p2p_set_exchange themselves; ccal_p2p_set_exchange stays as the override.
+int ccal_p2p_export2(ccal_ctx *c, int32_t world_size, int32_t rank, char blob_out[CCAL_P2P_BLOB_BYTES]) {
+    if (!blob_out) return fail(CCAL_E_ARG, "ccal_p2p_export2: NULL argument");
+    memset(blob_out, 0, CCAL_P2P_BLOB_BYTES);
+    int rc = ccal_p2p_export(c, world_size, rank, blob_out);
+    if (rc != CCAL_OK) return rc;
+    return ccal_device_uuid(c->device, blob_out + P2P_HANDLE_BYTES);
+}
+
+int ccal_p2p_connect2(ccal_ctx *c, const char *blobs, int64_t n_images_global) {
+    if (!c || !blobs) return fail(CCAL_E_ARG, "ccal_p2p_connect2: NULL argument");
+    if (!c->p2p) return fail(CCAL_E_STATE, "ccal_p2p_connect2: ccal_p2p_export2 has not been called");
+    const int W = c->p2p->world();
+    std::vector<char> handles((size_t)W * P2P_HANDLE_BYTES);
+    bool shared = false;
+    for (int r = 0; r < W; r++) {
+        memcpy(handles.data() + (size_t)r * P2P_HANDLE_BYTES, blobs + (size_t)r * CCAL_P2P_BLOB_BYTES, P2P_HANDLE_BYTES);
+        for (int q = 0; q < r; q++)
+            shared = shared || memcmp(blobs + (size_t)r * CCAL_P2P_BLOB_BYTES + P2P_HANDLE_BYTES,
+                                      blobs + (size_t)q * CCAL_P2P_BLOB_BYTES + P2P_HANDLE_BYTES, 16) == 0;
+    }
+    const int rc = ccal_p2p_connect(c, handles.data(), n_images_global);
+    if (rc != CCAL_OK) return rc;
+    c->p2p_shared_detected = shared;
+    c->p2p_no_fuse = c->p2p_mode == 1 || (c->p2p_mode == 0 && shared);
+    return CCAL_OK;
+}
+
+int ccal_p2p_shared_device(ccal_ctx *c) { return (c && c->p2p_shared_detected) ? 1 : 0; }
 
 int ccal_p2p_selftest(ccal_ctx *c, int32_t rounds) {
     if (!c || rounds < 1) return fail(CCAL_E_ARG, "ccal_p2p_selftest: bad argument");
@@ -349,8 +386,10 @@ int ccal_p2p_selftest(ccal_ctx *c, int32_t rounds) {
 
 int ccal_p2p_set_exchange(ccal_ctx *c, int32_t mode) {
     if (!c) return fail(CCAL_E_ARG, "ccal_p2p_set_exchange: ctx == NULL");
-    if (mode != 0 && mode != 1) return fail(CCAL_E_ARG, "ccal_p2p_set_exchange: mode is 0 (automatic) or 1 (one-workgroup exchange)");
-    c->p2p_no_fuse = mode == 1;
+    if (mode < 0 || mode > 2)
+        return fail(CCAL_E_ARG, "ccal_p2p_set_exchange: mode is 0 (automatic), 1 (one-workgroup exchange) or 2 (fused even on a shared device)");
+    c->p2p_mode = mode;
+    c->p2p_no_fuse = mode == 1 || (mode == 0 && c->p2p_shared_detected);
     c->graph_dirty = true;             // a captured solve holds the launches of the old mode
     return CCAL_OK;
 }
@@ -1576,6 +1615,31 @@ int ccal_time_sweep(ccal_ctx *c, int32_t reps, double *avg_us) {
     c->have_result = false;   // blk[0] heads now hold the timed point, not the fit's buffers
     *avg_us = 1000.0 * ms / reps;
     return CCAL_OK;
+}
+
+int ccal_debug_p2p_world(ccal_ctx *c, int32_t world, int32_t rounds, uint32_t seq0, const double *rows, double *sums) {
+    if (!c || !rows || !sums) return fail(CCAL_E_ARG, "ccal_debug_p2p_world: NULL argument");
+    if (world < 1 || world > P2P_MAX_RANKS || rounds < 1 || rounds > 4096) return fail(CCAL_E_ARG, "ccal_debug_p2p_world: 1..16 ranks, 1..4096 rounds");
+    HIPCHK(hipSetDevice(c->device));
+    int timed_out = 0;
+    HIPCHK(p2p_world_debug(c->stream, world, rounds, seq0, rows, sums, &timed_out));
+    if (timed_out) return fail(CCAL_E_COMM, "ccal_debug_p2p_world: an exchange timed out");
+    return CCAL_OK;
+}
+
+int ccal_debug_multi_set_epoch(int32_t n_dev, const int32_t *dev_ids, uint32_t epoch) {
+    if (!dev_ids || n_dev < 1) return fail(CCAL_E_ARG, "ccal_debug_multi_set_epoch: bad argument");
+    const std::vector<int> want(dev_ids, dev_ids + n_dev);
+    for (auto &m : t_multi) {
+        if (m.devices != want) continue;
+        for (ccal_ctx *x : m.ctx) {
+            HIPCHK(hipSetDevice(x->device));
+            HIPCHK(hipStreamSynchronize(x->stream));
+            if (x->p2p) HIPCHK(x->p2p->set_epoch(epoch));
+        }
+        return CCAL_OK;
+    }
+    return fail(CCAL_E_STATE, "ccal_debug_multi_set_epoch: no such device set on this thread (call ccal_calibrate_multi first)");
 }
 
 int ccal_debug_acc_sum(ccal_ctx *c, const double *rows, int32_t n_rows, int32_t replicas, double out[68]) {

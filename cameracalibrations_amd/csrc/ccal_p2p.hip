@@ -138,6 +138,70 @@ __global__ __launch_bounds__(256) void k_p2p_recv(P2PDev p, double *buf, int n) 
     if (tid == 0) __hip_atomic_store(p.epoch, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// diagnostics: the `world` workgroups of ONE launch act as the ranks of a node -- rank r = workgroup r with its own inbox in this
+// device's memory -- and run `rounds` consecutive exchanges of p2p_exchange_rows the way a series of solves numbers them (three
+// trials per solve, k = 1..3, then the next sequence number, starting at seq0).  All ranks are co-resident by construction
+// (world <= 16 workgroups), so this exercises the protocol itself at any world size on one GPU: tags, the four-slot rotation, the
+// rank-ordered sum, the 16-bit wrap of the sequence field in the tag.
+__global__ __launch_bounds__(256) void k_p2p_world_debug(const P2PDev *devs, int rounds, unsigned int seq0, const double *rows,
+                                                         double *sums) {
+    __shared__ double s_val[P2P_MAX_DOUBLES];
+    __shared__ double s_all[P2P_MAX_RANKS * P2P_MAX_DOUBLES];
+    const int tid = threadIdx.x, rank = blockIdx.x, world = gridDim.x;
+    const P2PDev p = devs[rank];
+    for (int rd = 0; rd < rounds; rd++) {
+        const unsigned int seq = seq0 + (unsigned)(rd / 3), k = 1u + (unsigned)(rd % 3);
+        if (tid < P2P_MAX_DOUBLES) s_val[tid] = rows[((size_t)rd * world + rank) * P2P_MAX_DOUBLES + tid];
+        __syncthreads();
+        const bool ok = p2p_exchange_rows(p, p2p_tag(seq, k), p2p_slot(seq, k), s_val, s_all, P2P_MAX_DOUBLES, tid, true);
+        if (tid < P2P_MAX_DOUBLES) sums[((size_t)rd * world + rank) * P2P_MAX_DOUBLES + tid] = s_val[tid];
+        __syncthreads();
+        if (!ok) return;                      // (workgroup-uniform; the peers time out in turn)
+    }
+}
+
+hipError_t p2p_world_debug(hipStream_t stream, int world, int rounds, unsigned int seq0, const double *rows_host, double *sums_host,
+                           int *timed_out) {
+    if (world < 1 || world > P2P_MAX_RANKS || rounds < 1) return hipErrorInvalidValue;
+    unsigned long long *boxes = nullptr;
+    P2PDev *d_devs = nullptr;
+    double *d_rows = nullptr, *d_sums = nullptr;
+    int *h_err = nullptr;
+    const size_t n = (size_t)rounds * world * P2P_MAX_DOUBLES;
+    hipError_t e;
+    auto done = [&](hipError_t r) {
+        (void)hipFree(boxes); (void)hipFree(d_devs); (void)hipFree(d_rows); (void)hipFree(d_sums); (void)hipHostFree(h_err);
+        return r;
+    };
+    if ((e = hipExtMallocWithFlags(reinterpret_cast<void **>(&boxes), (size_t)world * P2P_INBOX_WORDS * 8, hipDeviceMallocFinegrained)) != hipSuccess) return done(e);
+    if ((e = hipMemset(boxes, 0, (size_t)world * P2P_INBOX_WORDS * 8)) != hipSuccess) return done(e);
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&h_err), 64, hipHostMallocMapped)) != hipSuccess) return done(e);
+    *h_err = 0;
+    P2PDev devs[P2P_MAX_RANKS];
+    memset(devs, 0, sizeof devs);
+    for (int r = 0; r < world; r++) {
+        devs[r].inbox = boxes + (size_t)r * P2P_INBOX_WORDS;
+        for (int q = 0; q < world; q++) devs[r].peer[q] = boxes + (size_t)q * P2P_INBOX_WORDS;
+        devs[r].epoch = nullptr;
+        devs[r].err = h_err;
+        devs[r].budget = 200000000ll;         // 2 s
+        devs[r].world = world;
+        devs[r].rank = r;
+    }
+    if ((e = hipMalloc(reinterpret_cast<void **>(&d_devs), sizeof devs)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(reinterpret_cast<void **>(&d_rows), n * 8)) != hipSuccess) return done(e);
+    if ((e = hipMalloc(reinterpret_cast<void **>(&d_sums), n * 8)) != hipSuccess) return done(e);
+    if ((e = hipMemcpy(d_devs, devs, sizeof devs, hipMemcpyHostToDevice)) != hipSuccess) return done(e);
+    if ((e = hipMemcpy(d_rows, rows_host, n * 8, hipMemcpyHostToDevice)) != hipSuccess) return done(e);
+    if ((e = hipMemset(d_sums, 0, n * 8)) != hipSuccess) return done(e);
+    hipLaunchKernelGGL(k_p2p_world_debug, dim3(world), dim3(256), 0, stream, d_devs, rounds, seq0, d_rows, d_sums);
+    if ((e = hipGetLastError()) != hipSuccess) return done(e);
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return done(e);
+    if ((e = hipMemcpy(sums_host, d_sums, n * 8, hipMemcpyDeviceToHost)) != hipSuccess) return done(e);
+    *timed_out = *h_err;
+    return done(hipSuccess);
+}
+
 hipError_t launch_p2p_send(hipStream_t stream, const P2PDev &p, const double *buf, int n) {
     if (n < 1 || n > P2P_MAX_DOUBLES) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_p2p_send, dim3(1), dim3(256), 0, stream, p, buf, n);

@@ -63,6 +63,8 @@ class P2P {
     const P2PDev &dev() const { return dev_; }
     // 0 = no exchange has timed out since the last call (clears the flag); stream must be idle
     int check_and_clear(std::string &err);
+    // diagnostics: overwrite the solve sequence number (every rank of a fit must be given the same value; streams idle)
+    hipError_t set_epoch(unsigned int value) { return hipMemcpy(dev_.epoch, &value, sizeof value, hipMemcpyHostToDevice); }
 
   private:
     P2PDev dev_{};
@@ -70,6 +72,10 @@ class P2P {
     int device_ = 0;
 };
 
+// diagnostics (ccal_debug_p2p_world): `world` workgroups of one launch as the ranks of a node, `rounds` exchanges numbered like
+// consecutive solves from sequence number seq0; rows / sums [rounds][world][68] on the host
+hipError_t p2p_world_debug(hipStream_t stream, int world, int rounds, unsigned int seq0, const double *rows_host, double *sums_host,
+                           int *timed_out);
 // buf[0..n) <- sum over ranks (n <= 68), one workgroup on `stream`
 hipError_t launch_p2p_allreduce(hipStream_t stream, const P2PDev &p, double *buf, int n);
 // the same all-reduce as two kernels, for ranks whose kernels share one in-order queue: every such rank's send is

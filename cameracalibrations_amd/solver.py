@@ -73,24 +73,22 @@ class Solver:
     def init_p2p(self, world_size, rank, n_images_global, allgather_bytes, shared_device=None):
         """Direct xGMI row exchange between the GPUs of one node (no collective library).
         `allgather_bytes(b: bytes) -> list[bytes]` returns every rank's bytes in rank order (e.g. through
-        torch.distributed): the 64-byte inbox handle followed by the 16-byte id of the rank's device.  Two ranks
-        with the same device id share a GPU (a rehearsal on a one-GPU box): every rank then takes the
-        one-workgroup exchange (ccal_p2p_set_exchange), so that a waiting rank holds one compute unit and not a
-        grid; `shared_device` forces the answer.  Returns True when a device is shared."""
-        buf, uid = C.create_string_buffer(64), C.create_string_buffer(16)
-        rc = F.lib().ccal_p2p_export(self._h, int(world_size), int(rank), buf)
-        if rc == 0:
-            rc = F.lib().ccal_device_uuid(int(self.device), uid)
-        got = allgather_bytes(buf.raw + uid.raw if rc == 0 else bytes(80))   # the gather is collective: always join it
+        torch.distributed): one 80-byte blob per rank (ccal_p2p_export2: the inbox handle and the id of the rank's device).
+        The library itself notices two ranks with the same device id (a rehearsal on a one-GPU box) and then takes the
+        one-workgroup exchange, so that a waiting rank holds one compute unit and not a grid; `shared_device` overrides the
+        detection (False: the fused form whatever was detected).  Returns True when the one-workgroup exchange is in use."""
+        blob = C.create_string_buffer(80)
+        rc = F.lib().ccal_p2p_export2(self._h, int(world_size), int(rank), blob)
+        got = allgather_bytes(blob.raw if rc == 0 else bytes(80))   # the gather is collective: always join it
         F.check(rc)
         assert len(got) == world_size and all(len(h) == 80 for h in got)
         if any(h[:64] == bytes(64) for h in got):
             raise RuntimeError("init_p2p: a peer rank could not export its inbox")
-        ids = [h[64:] for h in got]
-        shared = len(set(ids)) < len(ids) if shared_device is None else bool(shared_device)
-        F.check(F.lib().ccal_p2p_connect(self._h, b"".join(h[:64] for h in got), int(n_images_global)))
-        F.check(F.lib().ccal_p2p_set_exchange(self._h, 1 if shared else 0))
-        return shared
+        F.check(F.lib().ccal_p2p_connect2(self._h, b"".join(got), int(n_images_global)))
+        if shared_device is not None:
+            F.check(F.lib().ccal_p2p_set_exchange(self._h, 1 if shared_device else 2))
+            return bool(shared_device)
+        return bool(F.lib().ccal_p2p_shared_device(self._h))
 
     def p2p_selftest(self, rounds=8):
         """Exchanges known rows `rounds` times and checks the sums (all ranks call it together)."""
@@ -247,6 +245,16 @@ class Solver:
         F.check(F.lib().ccal_debug_acc_sum(self._h, rp, rows.shape[0], int(replicas), o))
         return out
 
+    def debug_p2p_world(self, rows, seq0=0):
+        """Diagnostics: rows (rounds, world, 68) through `world` workgroups acting as the ranks of a node (ccal_debug_p2p_world)
+        -> what every rank holds after every exchange, (rounds, world, 68)."""
+        rows, rp = F.f64(rows)
+        rounds, world, n = rows.shape
+        assert n == 68
+        out, o = F.out64(rounds, world, 68)
+        F.check(F.lib().ccal_debug_p2p_world(self._h, int(world), int(rounds), int(seq0) & 0xFFFFFFFF, rp, o))
+        return out
+
     def time_sweep(self, reps=50):
         v = C.c_double(0)
         F.check(F.lib().ccal_time_sweep(self._h, int(reps), C.byref(v)))
@@ -285,6 +293,12 @@ def calibrate_multi(obj, img, image_size, devices, aspect=1.0, flags=0, max_iter
     d = st.asdict()
     d.update(intr=np.r_[K4, dist5], rvecs=rv, tvecs=tv, rms=rms.value, iters=iters.value)
     return status, d
+
+
+def debug_multi_set_epoch(devices, epoch):
+    """Diagnostics: set the solve sequence number of every shard of this thread's cached `calibrate_multi` device set."""
+    devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+    F.check(F.lib().ccal_debug_multi_set_epoch(len(devices), devs, int(epoch) & 0xFFFFFFFF))
 
 
 def fit_model(sz, objpoints, imgpointss, n_corners, with_distortion, aspect, device=0):

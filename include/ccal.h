@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CCAL_VERSION 101 /* 0.1.1: ccal_stats.solve_kernels_us, ccal_fit, ccal_set_graph, ccal_p2p_set_exchange, ccal_device_uuid */
+#define CCAL_VERSION 102 /* 0.1.2: ccal_p2p_export2 / ccal_p2p_connect2 (device id inside the blob), ccal_p2p_set_exchange mode 2 */
 
 /* status codes */
 #define CCAL_OK            0
@@ -131,6 +131,13 @@ int  ccal_comm_init_rank(ccal_ctx *ctx, int32_t world_size, int32_t rank, const 
  * Replaces any hook / RCCL communicator set before. */
 int  ccal_p2p_export(ccal_ctx *ctx, int32_t world_size, int32_t rank, char handle_out[64]);
 int  ccal_p2p_connect(ccal_ctx *ctx, const char *handles, int64_t n_images_global);
+/* The same pair with the rank's device id inside the blob (64-byte inbox handle + 16-byte device uuid; all-gather world x 80
+ * bytes): the library then sees for itself when two ranks share a GPU and takes the one-workgroup exchange (see
+ * ccal_p2p_set_exchange) without the caller's help.  ccal_p2p_shared_device: 1 if ccal_p2p_connect2 found such a pair. */
+#define CCAL_P2P_BLOB_BYTES 80
+int  ccal_p2p_export2(ccal_ctx *ctx, int32_t world_size, int32_t rank, char blob_out[CCAL_P2P_BLOB_BYTES]);
+int  ccal_p2p_connect2(ccal_ctx *ctx, const char *blobs, int64_t n_images_global);
+int  ccal_p2p_shared_device(ccal_ctx *ctx);
 /* `rounds` exchanges of known rows, checked on the host (every rank must call it with the same
  * count): CCAL_OK, or CCAL_E_COMM when a peer stayed silent or a sum came back wrong. */
 int  ccal_p2p_selftest(ccal_ctx *ctx, int32_t rounds);
@@ -139,8 +146,9 @@ int  ccal_p2p_selftest(ccal_ctx *ctx, int32_t rounds);
  * per trial otherwise.  mode 1: always the one-workgroup exchange; REQUIRED on every rank when ranks of several
  * processes share one GPU (rehearsals, time-shared devices): a rank that waits then holds one compute unit
  * instead of a whole grid that keeps the sender off the chip.  Same wire format either way; call it with the same
- * value on every rank, before the first solve.  ccal_device_uuid lets the ranks find out (all-gather the 16 bytes
- * next to the inbox handle; two equal ids = a shared device), as the Python mirror's Solver.init_p2p does. */
+ * value on every rank, before the first solve.  With ccal_p2p_export2 / ccal_p2p_connect2 mode 0 already includes the
+ * detection (two equal device ids in the blobs = a shared device); mode 2 keeps the fused form even then (tests of the
+ * fused kernels on a one-GPU box).  ccal_device_uuid serves callers of the 64-byte pair. */
 int  ccal_p2p_set_exchange(ccal_ctx *ctx, int32_t mode);
 int  ccal_device_uuid(int32_t device, char uuid_out[16]);
 
@@ -269,6 +277,15 @@ int  ccal_debug_image_grams(ccal_ctx *ctx, const double intr[CCAL_NINTR], const 
  * out[0..67] = the column sums (the last column carries no value; the error column, 63, turns NaN / +inf when a
  * NaN / out-of-range value was added). */
 int  ccal_debug_acc_sum(ccal_ctx *ctx, const double *rows, int32_t n_rows, int32_t replicas, double out[68]);
+/* the xGMI row exchange on its own, at any world size on one GPU: `world` (1..16) workgroups of ONE launch act as the ranks of a
+ * node (rank r = workgroup r, its own inbox in this device's memory) and run `rounds` consecutive exchanges numbered the way a
+ * series of solves numbers them (three trials per solve, then the next sequence number, starting at seq0 -- 0xFFFD.. crosses the
+ * 16-bit wrap of the sequence field in the tag).  rows / sums: [rounds][world][68] doubles on the host; sums[rd][r] = what rank
+ * r holds after exchange rd = the rank-ordered sum of rows[rd][0..world). */
+int  ccal_debug_p2p_world(ccal_ctx *ctx, int32_t world, int32_t rounds, uint32_t seq0, const double *rows, double *sums);
+/* overwrite the solve sequence number of every shard of this thread's cached ccal_calibrate_multi device set (same n_dev /
+ * dev_ids as the call that created it): lets a test run sharded solves across the tag's 16-bit wrap */
+int  ccal_debug_multi_set_epoch(int32_t n_dev, const int32_t *dev_ids, uint32_t epoch);
 /* current initial values held by the context: intr[9], rt [6,N] */
 int  ccal_get_init(ccal_ctx *ctx, double intr[CCAL_NINTR], double *rt_host);
 /* average device time (microseconds, HIP events on the context's stream) of `reps` launches

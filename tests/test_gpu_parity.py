@@ -1000,3 +1000,103 @@ def test_cached_contexts_are_released_at_thread_exit():
         free.append(torch.cuda.mem_get_info(0)[0])
     # the first thread pays for one-time runtime allocations; after that nothing may pile up
     assert free[-1] >= free[1] - (4 << 20), free
+
+
+@pytest.mark.parametrize("world", [2, 8, 16])
+def test_row_exchange_protocol_at_world_8_and_16_across_the_tag_wrap(world):
+    """`p2p_exchange_rows` (what ranks with a GPU each run, fused into k_lm_trial) at world sizes no multi-process test on one
+    GPU can reach: `world` workgroups of ONE launch act as the ranks of a node (ccal_debug_p2p_world), 24 consecutive exchanges
+    numbered like eight solves of three trials, starting at sequence number 0xFFFC so that the 16-bit sequence field of the tag
+    (ccal_p2p_dev.hpp:10) wraps in the middle.  Every rank must hold the RANK-ORDERED sum, bit for bit, after every exchange."""
+    rng = np.random.default_rng(world)
+    rows = rng.standard_normal((24, world, 68)) * 10.0 ** rng.integers(-8, 8, size=(24, world, 68))
+    with Solver(0) as s:
+        got = s.debug_p2p_world(rows, seq0=0xFFFC)
+    want = np.zeros((24, 68))
+    for r in range(world):
+        want = want + rows[:, r, :]             # ((r0 + r1) + r2) + ...: the order every rank adds in
+    for r in range(world):
+        assert np.array_equal(got[:, r, :], want), r
+
+
+def test_sharded_solves_across_the_exchange_epoch_wrap():
+    """Four sharded fits (two and three shards of one host thread: k_lm_send / k_lm_recv + the split focal all-reduce) with the
+    solve sequence number started at 0xFFFE: the tag's 16-bit sequence field wraps between them.  Every fit must return the
+    bits of the fit before the wrap."""
+    from cameracalibrations_amd import _ffi
+    from cameracalibrations_amd.solver import calibrate_multi, debug_multi_set_epoch
+    wl = syn.named_workload("C2", n_images=48)
+    for devs in ([0, 0], [0, 0, 0]):
+        st, base = calibrate_multi(wl.obj, wl.img, wl.image_size, devs, aspect=wl.aspect, flags=wl.flags, max_iter=REF[0], eps=REF[1])
+        assert st in (0, 1)
+        debug_multi_set_epoch(devs, 0xFFFE)
+        for rep in range(4):
+            st, r = calibrate_multi(wl.obj, wl.img, wl.image_size, devs, aspect=wl.aspect, flags=wl.flags, max_iter=REF[0], eps=REF[1])
+            assert st in (0, 1)
+            assert r["iters"] == base["iters"] and r["rms"] == base["rms"]
+            assert np.array_equal(r["intr"], base["intr"]) and np.array_equal(r["rvecs"], base["rvecs"]) and np.array_equal(r["tvecs"], base["tvecs"])
+        _ffi.lib().ccal_thread_cleanup()
+
+
+def test_pose_initialisation_of_a_2025_corner_board():
+    """No limit on n_corners (the reference puts none): a 45 x 45 board is 2025 corners per view -- 32 passes of 64 lanes in every
+    kernel, and 65 KB of normalised correspondences, more than a workgroup's LDS: k_init_extrinsics must take them from memory
+    (its LDSP = false form), both when the pixel-space homographies of the intrinsics stage are reused and when the poses
+    are asked for on their own (OpenCV's own sequence: DLT + polish on normalised points).  Against the oracle."""
+    rng = np.random.default_rng(7)
+    n1 = n2 = 45
+    obj = syn.board_template((n1, n2))
+    N = 3
+    intr = np.array([1600.0, 1600.0, 756.8, 995.4, 0, 0, 0, 0, 0])
+    rts, imgs = [], []
+    for i in range(N):
+        r = rng.uniform(-0.3, 0.3, 3)
+        t = np.array([-22.0 + rng.uniform(-2, 2), -22.0 + rng.uniform(-2, 2), 80.0 + rng.uniform(0, 20)])
+        proj = orc.project_points(obj, r, t, intr)
+        imgs.append(np.asarray(proj, dtype=np.float64) + rng.normal(0, 0.1, (n1 * n2, 2)))
+        rts.append(np.r_[r, t])
+    img = np.stack(imgs).astype(np.float32)
+    rt_or = np.array([np.r_[orc.find_extrinsics(obj, img[i], intr)] for i in range(N)])
+    with Solver(0) as s:
+        s.set_problem(obj, N, (1500, 2000), aspect=1.0, flags=0, max_iter=30, eps=1e-3)
+        s.set_image_points(img)
+        s.set_intrinsics(intr)                 # no intrinsics stage has run: OpenCV's own sequence on normalised points
+        s.init_extrinsics()
+        _, a = s.get_init()
+        s.init_intrinsics()                    # ... and with its pixel-space homographies at hand
+        s.set_intrinsics(intr)
+        s.init_extrinsics()
+        _, b = s.get_init()
+    for got in (a, b):
+        assert np.abs(got[:, :3] - rt_or[:, :3]).max() < 1e-7 and np.abs(got[:, 3:] - rt_or[:, 3:]).max() < 1e-5
+        assert np.abs(got - np.array(rts)).max() < 1e-2
+
+
+def test_sharded_initialisation_takes_the_form_of_the_whole_fit():
+    """The initialisation kernels have a latency form and a throughput form whose trial errors are summed differently; which
+    one runs follows from the GLOBAL image count: the first 550 images of a 1100-image fit (more images than the chip has
+    SIMDs), initialised as a shard of that fit, get the poses the whole fit computes for them BIT for bit -- on their own,
+    550 images would take the other form -- and the fit in two shards ends where the whole fit ends."""
+    from cameracalibrations_amd.solver import calibrate_multi
+    wl = syn.named_workload("C1", n_images=1100)
+    intr0 = np.array([1601.0, 1599.0, 749.5, 999.5, 0, 0, 0, 0, 0])
+    with _solver(wl, REF) as s:
+        s.set_intrinsics(intr0)
+        s.init_extrinsics()
+        _, whole = s.get_init()
+        st, rw = s.calibrate()
+    with Solver(0) as s:
+        s.set_problem(wl.obj, 550, wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=REF[0], eps=REF[1])
+        s.set_image_points(np.ascontiguousarray(wl.img[:550]))
+        s.set_allreduce(lambda buf, n, stream: 0, 1, 0, 1100)      # a shard of a 1100-image fit (sums of one rank: identity)
+        s.set_intrinsics(intr0)
+        s.init_extrinsics()
+        _, part = s.get_init()
+    assert np.array_equal(part, whole[:550])
+    st2, r2 = calibrate_multi(wl.obj, wl.img, wl.image_size, [0, 0], aspect=wl.aspect, flags=wl.flags, max_iter=REF[0], eps=REF[1])
+    assert st2 == st and r2["iters"] == rw["iters"] and abs(r2["rms"] - rw["rms"]) < 1e-12
+    # (the two ranks' rows are added as doubles after each was decoded from its exact accumulators: last-bit differences in the
+    #  reduced system, 1e-11 in the poses of the ill-conditioned views)
+    assert np.abs(r2["rvecs"] - rw["rvecs"]).max() < 1e-9 and np.abs(r2["tvecs"] - rw["tvecs"]).max() < 1e-8
+    from cameracalibrations_amd import _ffi
+    _ffi.lib().ccal_thread_cleanup()

@@ -144,3 +144,41 @@ def test_round_trip(tmp_path):
         assert np.abs(d.rvecs - c.rvecs).max() < 1e-14 and np.array_equal(d.tvecs, c.tvecs)
         assert abs(d.checker_size - c.checker_size) < 1e-15 * c.checker_size
         assert list(json.loads(f.read_text())) == CALIBRATION_IO_FIELDS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rotation", ["vector", "matrix"])
+def test_device_fit_survives_save_and_load(tmp_path, rotation):
+    """Row (f3) end to end on the device: fit on the GPU -> `save` -> `load` -> the loaded calibration's device maps against the
+    fitted one's (`src/io.jl:19-32`; the reference's own round trip, test/runtests.jl:88-98, compares `files` only).
+    rotation="vector" stores the fitted rotation vectors themselves (JSON floats round-trip binary64 exactly): every map is
+    BIT-equal.  rotation="matrix" stores R(r) and `load` takes the logarithm again: the vector comes back to a few ulp, the
+    maps to 1e-10 px / 1e-12 board units."""
+    golden = os.path.join(HERE, "golden", "example_corners.json")
+    ex = json.load(open(golden))
+    n_corners = tuple(ex["n_corners"])
+    imgpointss = [m for m in np.array(ex["corners"], dtype=np.float64)]
+    c, eps = cc.fit_corners(imgpointss, n_corners, 2.5, ex["image_size_wh"], files=ex["files"], rng=np.random.default_rng(3))
+    f = tmp_path / "calibration.json"
+    cc.save(str(f), c, rotation=rotation)
+    d = cc.load(str(f))
+    assert d.files == c.files and d.k == c.k and np.array_equal(d.f, c.f) and np.array_equal(d.c, c.c)
+    assert np.array_equal(d.tvecs, c.tvecs) and d.checker_size == c.checker_size
+    rng = np.random.default_rng(5)
+    xyz = np.stack([rng.uniform(0, 10, 40), rng.uniform(0, 20, 40), np.zeros(40)], axis=1)
+    rc = np.stack([rng.uniform(20, 350, 40), rng.uniform(20, 480, 40)], axis=1)
+    for i in range(1, len(c.files) + 1):
+        fwd_c, fwd_d = c([cc.XYZ(*p) for p in xyz], i), d([cc.XYZ(*p) for p in xyz], i)
+        inv_c, inv_d = c([cc.RowCol(*p) for p in rc], i), d([cc.RowCol(*p) for p in rc], i)
+        if rotation == "vector":
+            assert np.array_equal(d.rvecs, c.rvecs)
+            assert np.array_equal(np.asarray(fwd_c), np.asarray(fwd_d)) and np.array_equal(np.asarray(inv_c), np.asarray(inv_d))
+        else:
+            assert np.abs(d.rvecs - c.rvecs).max() < 1e-14
+            assert np.abs(np.asarray(fwd_c) - np.asarray(fwd_d)).max() < 1e-10
+            assert np.abs(np.asarray(inv_c) - np.asarray(inv_d)).max() < 1e-11
+    # the metrics of the loaded calibration on the same corners are the fitted one's
+    objp = cc.board_template(n_corners) * 2.5
+    e2 = cc.calculate_errors(d, imgpointss, objp, 2.5, ex["image_size_wh"], ex["files"], n_corners, rng=np.random.default_rng(3))
+    for k in ("reprojection", "projection", "distance", "inverse"):
+        assert abs(e2[k] - eps[k]) < (1e-15 if rotation == "vector" else 1e-9), (k, e2[k], eps[k])
