@@ -91,6 +91,7 @@ struct ccal_ctx {
     // stage bookkeeping
     bool have_problem = false, have_img = false, have_intr = false, have_ext = false, have_result = false;
     bool have_H = false;               // d_H holds k_init_homography's output for the current image points
+    bool fail0_clean = false;          // d_fail[0] is zero (no memset needed in front of the pose stage)
     bool intr_distorted = false;       // the initial intrinsics carry distortion (a caller's guess): no shortcut through d_H
     int init_hmode = 2;                // how k_init_extrinsics obtains the normalised homography when d_H is valid (CCAL_INIT_HMODE)
     double intr0[CCAL_NINTR] = {0};
@@ -652,6 +653,7 @@ static int init_intrinsics_b(ccal_ctx *c) {
     }
     if (!c->defer_sync && (rc = finish_init(c, true, false)) != CCAL_OK) return rc;
     c->have_intr = true;
+    c->fail0_clean = true;             // (focal_solve zeroes the pose stage's failure counter)
     c->intr_distorted = false;         // cvInitIntrinsicParams2D leaves the distortion at zero
     c->have_result = false;
     c->stats.t_init_intr_s = now_s() - c->run_t0;
@@ -670,7 +672,9 @@ int ccal_init_extrinsics(ccal_ctx *c) {
     if (!c->planar_z0) return fail(CCAL_E_NONPLANAR, "ccal_init_extrinsics: only planar z = 0 templates are supported");
     HIPCHK(hipSetDevice(c->device));
     const double t0 = now_s();
-    HIPCHK(hipMemsetAsync(c->d_fail, 0, sizeof(int), c->stream));     // word 0: failed poses (word 1: focal solve)
+    // word 0: failed poses (word 1: focal solve); the focal solve kernel of the intrinsics stage has already zeroed it
+    if (!c->fail0_clean) HIPCHK(hipMemsetAsync(c->d_fail, 0, sizeof(int), c->stream));
+    c->fail0_clean = false;
     // the pixel-space homographies of the intrinsics stage stand in for the second, normalised homography OpenCV computes
     // here whenever they exist for these corners and the intrinsics carry no distortion (k_init_extrinsics, HMODE)
     const bool use_H = c->have_H && !c->intr_distorted && c->init_hmode != 0;
@@ -722,6 +726,8 @@ static TrialLaunch base_launch(ccal_ctx *c) {
     t.trace = c->d_trace; t.host_result = c->h_st; t.host_progress = progress_word(c);
     t.intr0 = c->d_intr0; t.ext0 = c->d_ext0; t.ext0_stride = EXT; t.init = make_init(c);
     t.N = c->N; t.P = c->P;
+    // the first launch of every solve reports the initialisation's flags and start intrinsics to the host (finish_init_check)
+    t.init_fail = c->d_fail; t.host_init_intr = reinterpret_cast<double *>(c->h_flags + 4); t.host_init_fail = c->h_flags;
     return t;
 }
 
@@ -1126,13 +1132,17 @@ int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int
         const std::string lm_err = g_err;
         // One read-back for everything the host still needs -- the initialisation's flags and values, the poses --
         // through pinned memory, and one wait on a completion word instead of two stream synchronisations.
+        // (the initialisation's flags and values came to the host with the solve's first launch)
         const bool poses = lm_rc >= 0 && c->have_result && (rvecs || tvecs);
-        if ((rc = finish_init_enqueue(c)) < 0) break;
         if (poses) {
             if ((rc = stage_need(c, sizeof(double) * 8 * (size_t)c->N)) < 0) break;
             if ((rc = enqueue_pose_rows(c, static_cast<double *>(c->h_stage))) < 0) break;
+            if ((rc = signal_and_spin(c)) < 0) break;
+        } else if (lm_rc < 0) {
+            // the LM may not have got as far as its first launch, let alone waiting for its completion: fetch the flags the old way
+            (void)finish_init_enqueue(c);
+            (void)hipStreamSynchronize(c->stream);
         }
-        if ((rc = signal_and_spin(c)) < 0) break;
         // initialisation failures explain (and outrank) whatever the LM reported on garbage
         if ((rc = finish_init_check(c, !guess, true)) < 0) break;
         if ((rc = lm_rc) < 0) { g_err = lm_err; break; }
@@ -1168,10 +1178,12 @@ int ccal_fit(ccal_ctx *c) {
     do {
         if (!guess && (rc = ccal_init_intrinsics(c)) < 0) break;
         if ((rc = ccal_init_extrinsics(c)) < 0) break;
-        if ((rc = finish_init_enqueue(c)) < 0) break;
-        lm_rc = ccal_lm_run(c);
+        lm_rc = ccal_lm_run(c);        // (its first launch carries the init stages' flags and intrinsics to the host)
         const std::string lm_err = g_err;
-        if (lm_rc < 0) (void)hipStreamSynchronize(c->stream);     // (the LM did not wait for its own completion)
+        if (lm_rc < 0) {               // (the LM may not have reached its first launch, and did not wait for its own completion)
+            (void)finish_init_enqueue(c);
+            (void)hipStreamSynchronize(c->stream);
+        }
         // initialisation failures explain (and outrank) whatever the LM reported on garbage
         if ((rc = finish_init_check(c, !guess, true)) < 0) break;
         if ((rc = lm_rc) < 0) g_err = lm_err;

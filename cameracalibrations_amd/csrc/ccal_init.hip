@@ -534,6 +534,7 @@ __device__ void focal_solve(const double *red, double *__restrict__ intr0, int *
     intr0[3] = !height ? 0.5 : (height - 1) * 0.5;
     for (int a = 4; a < 9; a++) intr0[a] = 0.0;
     fail_count[1] = bad;
+    fail_count[0] = 0;                 // the pose stage that follows counts its failed views here
 }
 
 // intr0 != NULL: this GPU holds every image, the solve follows in the same launch (no all-reduce in between)

@@ -515,6 +515,9 @@ struct TrialArgs {
     int final_only;               // prologue only (detect termination, report to the host)
     int xchg_fused;               // image-sharded fit: the prologue exchanges the local row with the peer GPUs
     unsigned int *tail_cnt;       // [TAIL_CNT] "workgroup done" counters of the tail-advance flows (zero between launches)
+    const int *init_fail;         // first launch of a solve, workgroup 0: the initialisation's failure words (device) ...
+    double *host_init_intr;       // ... and the start intrinsics go to pinned host memory (a pipelined fit needs no read-back kernel)
+    int *host_init_fail;
     P2PDev p2p;                   // used by the exchanging instantiations only
 };
 
@@ -714,6 +717,12 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         }
     }
     if ((KIND == 0)) {
+        if (blockIdx.x == 0 && A.host_init_intr != nullptr) {
+            // what the initialisation stages left for the host: nine start intrinsics, four failure words (ccal_fit reads them
+            // after the solve; they used to travel by a kernel of their own between the pose stage and this launch)
+            if (tid < NINTR) __hip_atomic_store(A.host_init_intr + tid, A.intr0[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            else if (tid < NINTR + 4) __hip_atomic_store(A.host_init_fail + (tid - NINTR), A.init_fail[tid - NINTR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         lm_boot(&ls, A.init, A.intr0, tid);
         // no other workgroup of this launch reads the sequence number; the launches after it see seq + 1
         if constexpr (XCHG)
@@ -1289,6 +1298,7 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     a.final_only = t.final_only;
     a.xchg_fused = 0;
     a.tail_cnt = t.tail_cnt;
+    a.init_fail = t.init_fail; a.host_init_intr = t.host_init_intr; a.host_init_fail = t.host_init_fail;
     memset(&a.p2p, 0, sizeof a.p2p);
     const bool tail = t.tail != 0;
     if (tail && (t.final_only || t.row_in != nullptr || t.tail_cnt == nullptr)) return hipErrorInvalidValue;
