@@ -182,6 +182,7 @@ int ccal_create(int device, ccal_ctx **out) {
     HIPCHK(hipMemset(c->d_acc_scratch, 0, ACC_BYTES + TAIL_BYTES));
     HIPCHK(hipMalloc(&c->d_foc_red, sizeof(double) * NFOC));
     HIPCHK(hipMalloc(&c->d_fail, sizeof(int) * 4));
+    HIPCHK(hipMemset(c->d_fail, 0, sizeof(int) * 4));
     HIPCHK(hipMalloc(&c->d_intr0, sizeof(double) * 9));
     HIPCHK(hipMalloc(&c->d_intr_scratch, sizeof(double) * 9));
     HIPCHK(hipMalloc(&c->d_trace, sizeof(TraceRec) * c->max_trace));

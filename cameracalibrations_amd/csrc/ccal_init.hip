@@ -924,6 +924,7 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
 #pragma unroll
     for (int k = 0; k < 6; k++) finite = finite && (fabs(rt[k]) < 1.0e300);
     if (ok && !finite && lane == 0) atomicAdd(fail_count, 1);
+    if (i == 0 && lane == 0) fail_count[2] = 1;      // "fresh initialisation results": the next solve's first launch reports them to the host
     if (lane < 6) {
         double v = rt[0];
 #pragma unroll

@@ -33,7 +33,8 @@ struct TrialLaunch {              // one launch of k_lm_trial (see ccal_lm.hip)
     int tail = 0;                 // tail-advance flow: workgroup 0 advances the state machine at the END of this launch (no
                                   // row_in, no terminating launch); every launch of a solve must then use it
     unsigned int *tail_cnt = nullptr;   // [LM_TAIL_COUNTERS] zeroed words in device memory (zero again after every launch)
-    const int *init_fail = nullptr;     // first launch: the init stages' four failure words (device) and the start intrinsics are
+    int *init_fail = nullptr;           // first launch: the init stages' four failure words (device; word 2 = "a pose stage has run since
+                                        // the last report", cleared here) and the start intrinsics are
     double *host_init_intr = nullptr;   // copied to pinned host memory by workgroup 0 (all three set, or none)
     int *host_init_fail = nullptr;
 };

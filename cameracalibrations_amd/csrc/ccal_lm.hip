@@ -39,6 +39,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -495,31 +496,35 @@ __device__ __forceinline__ void acc_clear(long long *__restrict__ acc, int R, in
 
 // Everything one launch needs, by value (a solve is a graph of these launches).
 struct TrialArgs {
-    const float *obj, *img;
-    double *blk;
+    // ---- first 64 bytes: everything the first burst of loads of a launch needs (one line of the kernel-argument segment;
+    //      with -amdgpu-kernarg-preload-count=16 these sixteen dwords are in SGPRs when the wave starts) ----
     LmState *st;                  // [2], double-buffered by trial parity: S_k lives in st[k & 1]
     long long *acc;               // [3][R][ACC_ROW] exact accumulators: this trial adds into buffer k % 3,
                                   // its prologue reads buffer (k - 1) % 3, workgroup 0 clears buffer (k + 1) % 3
-    int R;                        // replicas per buffer
+    double *blk;
+    const float *img, *obj;
     const double *row_in;         // != NULL: the prologue takes the reduced system from this row of 68 doubles
                                   // (already summed across GPUs by RCCL / a host hook / k_lm_exchange) instead
-    TraceRec *trace;
-    LmState *host_result;
-    unsigned long long *host_progress;
+    int N, P, k;
+    int R;                        // replicas per buffer
+    // ---- the rest ----
     const double *intr0, *ext0;   // start values (first trial only)
     int ext0_stride;
-    LmInit init;
-    double *gram_out;
-    int N, P, k;
     int first;                    // k == 0: build S_0 instead of advancing
     int final_only;               // prologue only (detect termination, report to the host)
     int xchg_fused;               // image-sharded fit: the prologue exchanges the local row with the peer GPUs
+    TraceRec *trace;
+    LmState *host_result;
+    unsigned long long *host_progress;
+    double *gram_out;
+    LmInit init;
     unsigned int *tail_cnt;       // [TAIL_CNT] "workgroup done" counters of the tail-advance flows (zero between launches)
-    const int *init_fail;         // first launch of a solve, workgroup 0: the initialisation's failure words (device) ...
+    int *init_fail;               // first launch of a solve, workgroup 0: the initialisation's failure words (device) ...
     double *host_init_intr;       // ... and the start intrinsics go to pinned host memory (a pipelined fit needs no read-back kernel)
     int *host_init_fail;
     P2PDev p2p;                   // used by the exchanging instantiations only
 };
+static_assert(offsetof(TrialArgs, R) + sizeof(int) == 64, "the launch's first loads take their addresses from the first 64 bytes");
 
 // S_0: the state OpenCV's loop starts from
 __device__ void lm_boot(LmState *ls, const LmInit &init, const double *intr0, int tid) {
@@ -717,11 +722,18 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         }
     }
     if ((KIND == 0)) {
-        if (blockIdx.x == 0 && A.host_init_intr != nullptr) {
+        if (blockIdx.x == 0 && A.host_init_intr != nullptr && tid < NINTR + 4) {
             // what the initialisation stages left for the host: nine start intrinsics, four failure words (ccal_fit reads them
-            // after the solve; they used to travel by a kernel of their own between the pose stage and this launch)
-            if (tid < NINTR) __hip_atomic_store(A.host_init_intr + tid, A.intr0[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            else if (tid < NINTR + 4) __hip_atomic_store(A.host_init_fail + (tid - NINTR), A.init_fail[tid - NINTR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            // after the solve; they used to travel by a kernel of their own between the pose stage and this launch).  Only when
+            // a pose stage has run since the last report (its kernel raises word 2): stores to host memory hold the launch's
+            // end back by a PCIe round trip, which a solve that merely restarts from the same initial values need not pay.
+            const int fresh = A.init_fail[2];
+            const int word = tid < NINTR ? 0 : (tid == NINTR + 2 ? 0 : A.init_fail[tid - NINTR]);
+            if (fresh != 0) {
+                if (tid < NINTR) __hip_atomic_store(A.host_init_intr + tid, A.intr0[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                else __hip_atomic_store(A.host_init_fail + (tid - NINTR), word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (tid == NINTR + 2) A.init_fail[2] = 0;
+            }
         }
         lm_boot(&ls, A.init, A.intr0, tid);
         // no other workgroup of this launch reads the sequence number; the launches after it see seq + 1

@@ -13,7 +13,9 @@ def build_variant(name, defines):
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, name + ".so")
     srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES]
-    cmd = ["/opt/rocm/bin/hipcc", *B.FLAGS, "-shared", *["-D" + d for d in defines], "-o", out, *srcs, "-ldl"]
+    # an entry starting with '@' is passed to the compiler as it is (e.g. @-mllvm,@-amdgpu-kernarg-preload-count=16)
+    extra = [d[1:] if d.startswith("@") else "-D" + d for d in defines]
+    cmd = ["/opt/rocm/bin/hipcc", *B.FLAGS, "-shared", *extra, "-o", out, *srcs, "-ldl"]
     subprocess.check_call(cmd)
     return out
 
