@@ -750,6 +750,25 @@ def main():
     fit_ms = 1e3 * float(np.median(ts))
     rp = s.result()
     assert rp["rms"] == rf["rms"] and rp["iters"] == rf["iters"]
+    # the opt-in pose initialisation (ccal_set_pose_init 2: the polished pixel-space homography decomposed directly), timed the same way
+    s.set_pose_init(2)
+    s.fit()
+    ts2, te2 = [], []
+    for _ in range(20):
+        t2 = time.perf_counter()
+        s.fit()
+        ts2.append(time.perf_counter() - t2)
+    r2 = s.result()
+    for _ in range(10):
+        s.init_intrinsics()
+        t2 = time.perf_counter()
+        s.init_extrinsics()
+        te2.append(time.perf_counter() - t2)
+    fast_init = {"full_fit_ms": 1e3 * float(np.median(ts2)), "extrinsics_ms": 1e3 * float(np.median(te2)),
+                 "rms_minus_default": r2["rms"] - rp["rms"], "iters": int(r2["iters"]),
+                 "what": "ccal_set_pose_init(2): no second homography in the pose stage; same optimum for views whose pose polish "
+                         "converges, not OpenCV's trajectory for a view that exhausts its 20 iterations (DESIGN.md section 7) -- opt-in"}
+    s.set_pose_init(1)
 
     # converged criteria (100, 1e-10): iters-to-tol
     rt, tight_ms = None, None
@@ -793,7 +812,7 @@ def main():
             "config": config_block(wl, model, cfg_index, N, n_total, world, comm_kind, CRITERIA, strong),
             "lm": lm_block(r, rt, tight_ms),
             "init": {"intrinsics_ms": 1e3 * rf["t_init_intr_s"], "extrinsics_ms": 1e3 * rf["t_init_extr_s"], "full_fit_ms": fit_ms,
-                     "full_fit_stage_by_stage_ms": staged_ms},
+                     "full_fit_stage_by_stage_ms": staged_ms, "pose_init_mode": 1, "pose_init_mode_2": fast_init},
             "roofline": roofline_block(N, P, K, sweep_us, n_timed, sweep_us_b2b, 1e3 * ev_s,
                                        "ccal::k_lm_trial<%s, false, 1>" % ("true" if world > 1 else "false")),
             "parity": "device == oracle (CPU restatement of OpenCV 4.10 from the published algorithm) in tests/; no run of OpenCV "

@@ -87,6 +87,7 @@ SIGNATURES = {
     "ccal_fit": (C.c_int, [C.c_void_p]),
     "ccal_set_sweep_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "ccal_set_graph": (C.c_int, [C.c_void_p, C.c_int32]),
+    "ccal_set_pose_init": (C.c_int, [C.c_void_p, C.c_int32]),
     "ccal_get_result": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.POINTER(Stats)]),
     "ccal_get_trace": (C.c_int, [C.c_void_p, C.POINTER(Trace), C.c_int32, C.POINTER(C.c_int32)]),
     "ccal_calibrate": (C.c_int, [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_uint32,

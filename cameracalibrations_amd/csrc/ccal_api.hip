@@ -93,7 +93,8 @@ struct ccal_ctx {
     bool have_H = false;               // d_H holds k_init_homography's output for the current image points
     bool fail0_clean = false;          // d_fail[0] is zero (no memset needed in front of the pose stage)
     bool intr_distorted = false;       // the initial intrinsics carry distortion (a caller's guess): no shortcut through d_H
-    int init_hmode = 2;                // how k_init_extrinsics obtains the normalised homography when d_H is valid (CCAL_INIT_HMODE)
+    int init_hmode = 1;                // how k_init_extrinsics obtains the normalised homography when d_H is valid: 1 = OpenCV's sequence
+                                       // with the DLT reused, 2 = the polished pixel-space homography decomposed directly (ccal_set_pose_init)
     double intr0[CCAL_NINTR] = {0};
     ccal_stats stats{};
     // multi-GPU
@@ -431,7 +432,7 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
         HIPCHK(hipMalloc(&c->d_obj, sizeof(float) * 3 * P));
         HIPCHK(hipMalloc(&c->d_ext0, sizeof(double) * n * EXT));
         HIPCHK(hipMalloc(&c->d_blk, sizeof(double) * 2 * n * BLK));
-        HIPCHK(hipMalloc(&c->d_H, sizeof(double) * n * 9));
+        HIPCHK(hipMalloc(&c->d_H, sizeof(double) * n * 18));    // per image: polished homography | DLT result
         HIPCHK(hipMalloc(&c->d_foc_partials, sizeof(double) * n * NFOC));
         c->n_cap = n;
         c->p_cap = P;
@@ -972,6 +973,13 @@ int ccal_lm_run(ccal_ctx *c) {
         if ((rc = lm_wait(c)) != CCAL_OK) return rc;
     }
     return lm_end(c);
+}
+
+int ccal_set_pose_init(ccal_ctx *c, int32_t mode) {
+    if (!c) return fail(CCAL_E_ARG, "ccal_set_pose_init: ctx == NULL");
+    if (mode < 0 || mode > 2) return fail(CCAL_E_ARG, "ccal_set_pose_init: mode is 0, 1 or 2");
+    c->init_hmode = mode;
+    return CCAL_OK;
 }
 
 int ccal_set_graph(ccal_ctx *c, int32_t enable) {

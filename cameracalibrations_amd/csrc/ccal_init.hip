@@ -334,7 +334,7 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, d
 // [OCV-K findHomography(method 0)]: per-axis normalised DLT (smallest eigenvector of LtL by
 // shifted inverse iteration) + LM polish.  Every lane returns the same H.  false = degenerate.
 template <bool SPEC, class Pts>
-__device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch, double H[9]) {
+__device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch, double H[9], double *H_dlt = nullptr) {
     HSTAMP(0);
     double cM0 = 0, cM1 = 0, cm0 = 0, cm1 = 0;
     for (int c0 = 0; c0 < P; c0 += 64) {
@@ -450,6 +450,12 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch
 #pragma unroll
     for (int k = 0; k < 9; k++) H[k] *= s;
     HSTAMP(4);
+    if (H_dlt != nullptr && lane < 9) {           // the DLT's result before the polish (every lane holds the same H)
+        double v = H[0];
+#pragma unroll
+        for (int k = 1; k < 9; k++) v = (lane == k) ? H[k] : v;
+        H_dlt[lane] = v;
+    }
     if (P > 4) {
         homog_refine<SPEC>(pts, P, lane, scratch, H);
         H[8] = 1.0;
@@ -464,6 +470,8 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch
 // ---------------------------------------------------------------------------------------
 // A4: homography per image + its two rows of the focal-length least squares
 // ---------------------------------------------------------------------------------------
+// H_out [N][2][9]: the polished homography (what the focal-length least squares uses) and, behind it, the DLT's result before
+// the polish (what k_init_extrinsics starts OpenCV's second polish from, HMODE 1)
 template <bool SPEC>
 __global__ __launch_bounds__(64) void k_init_homography(const float *__restrict__ obj, const float *__restrict__ img,
                                                          double *__restrict__ H_out, double *__restrict__ foc, int N,
@@ -474,8 +482,12 @@ __global__ __launch_bounds__(64) void k_init_homography(const float *__restrict_
     CachedPoints<RawPoints> pts;
     pts.init(raw, lane, P);
     double H[9];
-    const bool ok = wave_homography<SPEC>(pts, P, lane, s_sums, H);
-    if (lane < 9) H_out[(size_t)9 * i + lane] = ok ? H[lane] : 0.0;
+    if (lane < 9) H_out[(size_t)18 * i + 9 + lane] = 0.0;       // (a homography that fails before the polish leaves zeros)
+    const bool ok = wave_homography<SPEC>(pts, P, lane, s_sums, H, H_out + (size_t)18 * i + 9);
+    if (lane < 9) {
+        H_out[(size_t)18 * i + lane] = ok ? H[lane] : 0.0;
+        if (!ok) H_out[(size_t)18 * i + 9 + lane] = 0.0;
+    }
     // [OCV-K cvInitIntrinsicParams2D]
     const double a2 = !width ? 0.5 : (width - 1) * 0.5, a5 = !height ? 0.5 : (height - 1) * 0.5;
     H[0] -= H[6] * a2; H[1] -= H[7] * a2; H[2] -= H[8] * a2;
@@ -681,11 +693,15 @@ __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int
 // HMODE: where the normalised homography OpenCV computes before the polish comes from.
 //   0  [OCV-K] findHomography on the normalised points: DLT + LMSolver polish (the only form that works without a stored
 //      pixel-space homography, or with a distorted intrinsic guess)
-//   1  k_init_homography has just stored this image's polished PIXEL-space homography H_pix (board -> pixels); with zero
-//      distortion the board -> normalised-points homography is K^-1 H_pix T_c (T_c: the template's centring) up to the
-//      re-weighting of the residuals by (1/fx, 1/fy): the DLT is skipped and LMSolver's polish starts there
-//   2  ... and is skipped too: K^-1 H_pix T_c is decomposed directly, the 6-parameter pose polish that follows absorbs the
-//      difference (it converges to the pose optimum of the same reprojection error from either start)
+//   1  OpenCV's sequence with the DLT taken from k_init_homography: findHomography normalises both point sets per axis (centroid,
+//      mean absolute deviation) before the DLT, and the normalised image points (u - cx) / fx are a per-axis affine map of the
+//      pixel coordinates, so the DLT solves the SAME system for both and its result on normalised points is K^-1 H_dlt T_c
+//      (H_dlt: the pixel-space DLT result before its polish; T_c: the template's centring) up to the float32 rounding of the
+//      normalised points.  LMSolver's polish then runs on the normalised points exactly as in form 0.
+//   2  the polished pixel-space homography H_pix stands in for the whole second homography: K^-1 H_pix T_c is decomposed
+//      directly and the 6-parameter pose polish that follows absorbs the difference.  Views whose pose polish converges end at
+//      the same optimum (1e-11); a view that exhausts CvLevMarq's 20 iterations ends where 20 iterations take it from the
+//      slightly different start -- opt-in (ccal_set_pose_init), not OpenCV's trajectory for such views
 // LDSP = the normalised correspondences are staged in LDS (32 P bytes); false: read through NormPoints (any P).
 template <bool SPEC, int HMODE, bool LDSP>
 __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const float *__restrict__ obj, const float *__restrict__ img,
@@ -726,7 +742,7 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
         // H = K^-1 H_pix T_c, scaled to H[8] = 1 (every lane the same bits); a failed pixel-space homography was stored as zeros
         double Hp[9];
 #pragma unroll
-        for (int k = 0; k < 9; k++) Hp[k] = H_pix[(size_t)9 * i + k];
+        for (int k = 0; k < 9; k++) Hp[k] = H_pix[(size_t)18 * i + (HMODE == 1 ? 9 : 0) + k];
         const double ifx = 1.0 / pts.in[0], ify = 1.0 / pts.in[1];
         double G[9];
 #pragma unroll

@@ -1256,7 +1256,12 @@ int lm_sweep_blocks(int N) { return (N + WAVES - 1) / WAVES; }
 // duration in a solve, wpi 1 / 2 / 4 -- 100 images: 10.6 / 9.4 / 8.2 us; 500: 11.0 / 10.3 / 11.4; 1000: 12.9 / 12.9 / 12.9:
 // profiles/r04_pass_parallel_probe.txt).  CCAL_WPI = 1 / 2 / 4 forces a value for experiments, CCAL_WPI_CAP the grid limit.
 int lm_waves_per_image(int N, int P, bool fused) {
-    if (P <= 64) return 1;
+    int min_p = 65;                               // boards of one 64-corner pass stay one wave per image (CCAL_WPI_MINP: experiments)
+    if (const char *e = getenv("CCAL_WPI_MINP")) {
+        const int v = atoi(e);
+        if (v >= 8) min_p = v;
+    }
+    if (P < min_p) return 1;
     static int cus[16] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;

@@ -137,6 +137,11 @@ class Solver:
     def set_sweep_timing(self, enable=True):
         F.check(F.lib().ccal_set_sweep_timing(self._h, int(bool(enable))))
 
+    def set_pose_init(self, mode):
+        """0 = OpenCV's own sequence for the pose stage's homography, 1 (default) = the same with the DLT reused from the
+        intrinsics stage, 2 = the polished pixel-space homography decomposed directly (faster; see include/ccal.h)"""
+        F.check(F.lib().ccal_set_pose_init(self._h, int(mode)))
+
     def set_graph(self, enable=True):
         """replay a solve as one hipGraph (default) or launch it kernel by kernel"""
         F.check(F.lib().ccal_set_graph(self._h, int(bool(enable))))

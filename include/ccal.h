@@ -176,6 +176,16 @@ int  ccal_lm_run(ccal_ctx *ctx);
 /* A solve is replayed as one hipGraph (default; CCAL_NO_GRAPH=1 in the environment turns that off at ccal_create) or
  * launched kernel by kernel: same kernels, same results, different host cost. */
 int  ccal_set_graph(ccal_ctx *ctx, int32_t enable);
+/* How ccal_init_extrinsics obtains the board -> normalised-image homography OpenCV's cvFindExtrinsicCameraParams2 computes before
+ * its pose polish, when the intrinsics stage has run on the same corners (otherwise always mode 0):
+ *   0  OpenCV's own sequence: DLT + LMSolver polish on the normalised points
+ *   1  (default) the same sequence with the DLT's result taken from the intrinsics stage's pixel-space DLT (the two DLTs solve the
+ *      same per-axis-normalised system): OpenCV's trajectory to ~1e-10
+ *   2  the intrinsics stage's POLISHED pixel-space homography decomposed directly, no second polish: 15 % less time in the pose
+ *      stage; views whose 6-parameter polish converges end at the same pose (1e-11), a view that exhausts CvLevMarq's 20
+ *      iterations ends where they take it from the slightly different start (seen: 2e-4 rad on one view of a model-mismatched
+ *      set, 8e-7 px in the RMS of the fit that follows) -- not OpenCV's trajectory for such views */
+int  ccal_set_pose_init(ccal_ctx *ctx, int32_t mode);
 /* A4 + A5 + A6-A9 as ONE pipeline on the problem and image points already set (e.g. a device pointer): the stages are
  * enqueued back to back and the host waits once.  Same results as the three calls above; their per-stage times in
  * ccal_stats then only cover the enqueueing. */

@@ -30,7 +30,7 @@ for name in a.workloads.split(","):
     rt0 = np.array([np.concatenate(orc.find_extrinsics(wl.obj, wl.img[i], intr0)) for i in range(n_or)])
     ro = orc.calibrate(wl.obj, wl.img, wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=30, eps=1e-3, solver="schur")
     img = torch.from_numpy(np.ascontiguousarray(wl.img)).to("cuda:0")
-    for hmode in (0, 1, 2):
+    for hmode in (0, 1, 2):  # 1 = from the pixel-space DLT result since the second half of round 4
         os.environ["CCAL_INIT_HMODE"] = str(hmode)
         with Solver(0) as s:
             s.set_problem(wl.obj, wl.n_images, wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=30, eps=1e-3)
