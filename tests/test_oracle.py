@@ -256,3 +256,34 @@ def test_oracle_matches_opencv_when_available(golden_dir):
         assert np.abs(np.ravel(dist)[:5] - ro["intr"][4:]).max() < 1e-4
         assert np.abs(np.array(rvecs).reshape(-1, 3) - ro["rvecs"]).max() < 1e-4
         assert np.abs(np.array(tvecs).reshape(-1, 3) - ro["tvecs"]).max() < 1e-3
+
+
+def test_dlt_on_normalised_points_is_the_pixel_space_dlt_mapped_through_the_intrinsics():
+    """What the device's default pose stage relies on (k_init_extrinsics HMODE 1): findHomography normalises
+    both point sets per axis (centroid, mean absolute deviation) before its DLT, and the normalised image points (u - cx) / fx are
+    a per-axis affine map of the pixel coordinates -- so the DLT of board -> normalised points is K^-1 H_dlt T_c, with H_dlt the DLT
+    of board -> pixels and T_c the template's centring, up to the float32 rounding of the normalised points (1e-7), whatever the
+    noise and however unequal fx and fy.  (The POLISHED homographies do not correspond like that: the two polishes minimise
+    differently weighted errors -- which is why only the DLT is reused.)"""
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)      # noqa: E731
+    for name, n, fx, fy in (("C3", 8, 1610.0, 1600.0), ("C5", 4, 1400.0, 1750.0)):
+        wl = syn.named_workload(name, n_images=n)
+        obj = wl.obj.astype(np.float64)
+        cM = obj[:, :2].mean(axis=0)
+        cx, cy = 756.8, 995.4
+        Kinv = np.array([[1 / fx, 0, -cx / fx], [0, 1 / fy, -cy / fy], [0, 0, 1.0]])
+        Tc = np.array([[1, 0, cM[0]], [0, 1, cM[1]], [0, 0, 1.0]])
+        for i in range(n):
+            uv = wl.img[i].astype(np.float64)
+            Hp = orc.find_homography(f32(obj[:, :2]), uv, refine=False)
+            mn = np.stack([f32((uv[:, 0] - cx) / fx), f32((uv[:, 1] - cy) / fy)], axis=1)
+            Hn = orc.find_homography(f32(obj[:, :2] - cM), mn, refine=False)
+            G = Kinv @ Hp @ Tc
+            G /= G[2, 2]
+            assert np.abs(G - Hn / Hn[2, 2]).max() < 1e-7 * np.abs(Hn).max(), (name, i)      # (seen: 6e-9)
+            # ... while the polished homographies differ by more than that as soon as the data carry noise
+            Hp_r = orc.find_homography(f32(obj[:, :2]), uv, refine=True)
+            Hn_r = orc.find_homography(f32(obj[:, :2] - cM), mn, refine=True)
+            Gr = Kinv @ Hp_r @ Tc
+            dpol = np.abs(Gr / Gr[2, 2] - Hn_r / Hn_r[2, 2]).max()
+            assert 1e-7 < dpol < 1e-3, (name, i, dpol)                                           # (seen: 1e-5 ... 9e-5)
