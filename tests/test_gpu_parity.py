@@ -1170,3 +1170,23 @@ def test_fast_pose_init_is_the_same_optimum_for_views_that_converge():
     d = np.abs(rt - rt0).max(axis=1)
     assert (d > 1e-7).sum() <= 1 and d.max() < 1e-3
     assert r["iters"] == ro["iters"] and abs(r["rms"] - ro["rms"]) < 1e-6
+
+
+def test_split_images_in_a_sharded_fit():
+    """The pass-parallel sweep (four waves per 150-corner image) inside a sharded fit: 40 views of the 15 x 10 board in two and
+    in three shards of one host thread (the exchanging instantiations of k_lm_trial with WPI = 4) against the one-GPU fit and
+    the oracle."""
+    from cameracalibrations_amd import _ffi
+    from cameracalibrations_amd.solver import calibrate_multi
+    wl = syn.named_workload("C5", n_images=40)
+    ro = _oracle(wl, REF)
+    with _solver(wl, REF) as s:
+        _, base = s.calibrate()
+    _check_against_oracle(base, ro)
+    for devs in ([0, 0], [0, 0, 0]):
+        st, r = calibrate_multi(wl.obj, wl.img, wl.image_size, devs, aspect=wl.aspect, flags=wl.flags, max_iter=REF[0], eps=REF[1])
+        assert st in (0, 1)
+        _check_against_oracle(r, ro)
+        assert r["iters"] == base["iters"] and abs(r["rms"] - base["rms"]) < 1e-12
+        assert np.abs(r["rvecs"] - base["rvecs"]).max() < 1e-9 and np.abs(r["tvecs"] - base["tvecs"]).max() < 1e-8
+        _ffi.lib().ccal_thread_cleanup()
