@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6    # FP64 vector (= FP64 matrix) peak: 256 CUs x 128 flop/clk x 2.4 GHz
 # the clock these launches actually hold (s_memtime / s_memrealtime stamps, tools/stamps.py): 2.32 GHz with one wave per SIMD
-# (C3, profiles/r03_wave_stamps.json), 2.1 GHz under sustained FP64 load (C5, profiles/r03_c5_pmc_utilisation_summary.json)
+# (C3, profiles/r04_wave_stamps.json: 2.30-2.32), 2.1 GHz under sustained FP64 load (C5, profiles/r04_c5_pmc_utilisation_summary.json: SQ_WAVE_CYCLES over the waves' lifetime)
 CLOCK_GHZ_LATENCY, CLOCK_GHZ_FP64_LOAD, CLOCK_GHZ_PEAK = 2.32, 2.1, 2.4
 KERNEL_BOUNDARY_US = 1.45  # dependent kernel boundary, same stream (guide, "boundary" row of the price list)
 METRIC = "corner-residuals/sec + LM iters-to-tol, 1000 imgs x 9x6 corners, 1/2/4/8 GPU"
@@ -561,7 +561,7 @@ def shard(wl, world, rank):
 
 
 # Latency floor of ONE LM trial, from quantities the kernel does not choose (measured constants: the guide's price list
-# and profiles/r02_latency_probe.txt, tools/lat_probe.hip): what any one-launch-per-trial design pays when every image
+# and profiles/r04_latency_probe.txt, tools/lat_probe.hip): what any one-launch-per-trial design pays when every image
 # has a SIMD to itself (the C3 regime).  Not this kernel's own instruction stream: the kernel sits well above it.
 CLOCK_GHZ = CLOCK_GHZ_LATENCY   # measured in-kernel clock of the one-wave-per-SIMD launches
 LAT = {"fma": 4.2, "rcp": 16.2, "rsq": 16.2, "dpp": 12.2, "readlane": 28.2, "lds_round_trip": 128.0,   # cycles (profiles/r04_latency_probe.txt)
