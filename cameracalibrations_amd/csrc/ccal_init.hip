@@ -5,7 +5,8 @@
 //   A4  cvInitIntrinsicParams2D : per-image homography board -> image, focal lengths from the
 //       orthogonality constraints of its columns
 //   A5  cvFindExtrinsicCameraParams2, planar branch: homography on normalised points,
-//       decomposition, orthonormalisation, 6-parameter LM polish
+//       decomposition, orthonormalisation, 6-parameter LM polish; the homography's DLT is
+//       taken from A4's pixel-space DLT by default (k_init_extrinsics HMODE 1: same system, OpenCV's trajectory)
 //
 // Mapping: ONE 64-lane workgroup (= one wavefront) per image, one lane per corner; the normal equations of these
 // small problems (24-30 distinct sums over the corners) are formed per lane and summed over the lanes by a

@@ -28,6 +28,11 @@
 //   k_lm_send / k_lm_recv  the same exchange in two stream-ordered halves for shards that share one in-order
 //                stream (ccal_calibrate_multi with a device listed more than once).
 //
+//                Instantiations k_lm_trial<FLOW, LOOP, KIND, WPI>: looping grid or one image group per workgroup; first / later /
+//                terminating launch; WPI = 2 or 4 waves per image for boards of more than 64 corners while the split grid is at
+//                most one workgroup per compute unit (each wave takes an even share of the corners, the partial Grams meet in
+//                LDS); FLOW = the prologue forms described here (shipped) or the tail-advance experiment of round 4
+//                (-DCCAL_EXP_TAIL builds only: profiles/r04_tail_advance_probe.txt).
 // A solve of T trials is T + 1 launches of k_lm_trial (the last one runs the prologue only and
 // leaves the accumulators cleared for the next solve).
 // A rejected step costs one extra sweep of the accepted point with the larger lambda.
