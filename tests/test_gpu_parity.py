@@ -1070,6 +1070,14 @@ def test_pose_initialisation_of_a_2025_corner_board():
     for got in (a, b):
         assert np.abs(got[:, :3] - rt_or[:, :3]).max() < 1e-7 and np.abs(got[:, 3:] - rt_or[:, 3:]).max() < 1e-5
         assert np.abs(got - np.array(rts)).max() < 1e-2
+    # ... and the whole fit of such a board (32 passes per image, split over four waves by the pass-parallel sweep) against the oracle
+    ro = orc.calibrate(obj, img, (1500, 2000), aspect=1.0, flags=syn.FIX_K3, max_iter=30, eps=1e-3, solver="schur")
+    with Solver(0) as s:
+        s.set_problem(obj, N, (1500, 2000), aspect=1.0, flags=syn.FIX_K3, max_iter=30, eps=1e-3)
+        s.set_image_points(img)
+        st, r = s.calibrate()
+    assert st in (0, 1) and r["iters"] == ro["iters"] and abs(r["rms"] - ro["rms"]) < 1e-8
+    assert np.abs(r["intr"][:4] - ro["intr"][:4]).max() / ro["intr"][1] < 1e-6 and np.abs(r["rvecs"] - ro["rvecs"]).max() < 1e-5
 
 
 def test_sharded_initialisation_takes_the_form_of_the_whole_fit():
