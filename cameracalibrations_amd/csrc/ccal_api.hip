@@ -90,6 +90,10 @@ struct ccal_ctx {
     int *h_flags = nullptr;
     // stage bookkeeping
     bool have_problem = false, have_img = false, have_intr = false, have_ext = false, have_result = false;
+    long long *d_foc_acc = nullptr;    // [2][LM_FOC_ACC_WORDS] exact focal sums of the intrinsics stage (single GPU): two buffers rotate
+    int foc_buf = 0;                   // the buffer the next intrinsics stage adds into
+    bool foc_dirty = true;             // the buffers are not known to be zero
+    bool focal_pending = false;        // pipeline: the focal solve of the last intrinsics stage has been left to the pose kernel's prologue
     bool have_H = false;               // d_H holds k_init_homography's output for the current image points
     bool fail0_clean = false;          // d_fail[0] is zero (no memset needed in front of the pose stage)
     bool intr_distorted = false;       // the initial intrinsics carry distortion (a caller's guess): no shortcut through d_H
@@ -133,6 +137,14 @@ struct ccal_ctx {
     long run_max_trials = 0, run_trials = 0;
     bool run_graphed = false;
 };
+
+// a pipeline that left its focal solve to the pose kernel and never launched it: the accumulators are in an unknown state
+static void drop_pending_focal(ccal_ctx *c) {
+    if (c->focal_pending) {
+        c->focal_pending = false;
+        c->foc_dirty = true;
+    }
+}
 
 static void free_problem_buffers(ccal_ctx *c) {
     (void)hipFree(c->d_obj); (void)hipFree(c->d_img_own); (void)hipFree(c->d_ext0); (void)hipFree(c->d_blk);
@@ -182,6 +194,7 @@ int ccal_create(int device, ccal_ctx **out) {
     HIPCHK(hipMalloc(&c->d_acc_scratch, ACC_BYTES + TAIL_BYTES));
     HIPCHK(hipMemset(c->d_acc_scratch, 0, ACC_BYTES + TAIL_BYTES));
     HIPCHK(hipMalloc(&c->d_foc_red, sizeof(double) * NFOC));
+    HIPCHK(hipMalloc(&c->d_foc_acc, sizeof(long long) * 2 * LM_FOC_ACC_WORDS));
     HIPCHK(hipMalloc(&c->d_fail, sizeof(int) * 4));
     HIPCHK(hipMemset(c->d_fail, 0, sizeof(int) * 4));
     HIPCHK(hipMalloc(&c->d_intr0, sizeof(double) * 9));
@@ -213,7 +226,7 @@ void ccal_destroy(ccal_ctx *c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     free_problem_buffers(c);
-    (void)hipFree(c->d_st); (void)hipFree(c->d_st_scratch); (void)hipFree(c->d_red); (void)hipFree(c->d_foc_red); (void)hipFree(c->d_fail);
+    (void)hipFree(c->d_st); (void)hipFree(c->d_st_scratch); (void)hipFree(c->d_red); (void)hipFree(c->d_foc_red); (void)hipFree(c->d_foc_acc); (void)hipFree(c->d_fail);
     (void)hipFree(c->d_acc); (void)hipFree(c->d_acc_scratch);
     (void)hipFree(c->d_trace); (void)hipFree(c->d_intr0); (void)hipFree(c->d_intr_scratch);
     if (c->g_first) (void)hipGraphExecDestroy(c->g_first);
@@ -456,6 +469,7 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
     c->have_problem = true;
     c->have_img = c->have_intr = c->have_ext = c->have_result = false;
     c->have_H = false;
+    drop_pending_focal(c);
     c->d_img = nullptr;
     memset(&c->stats, 0, sizeof c->stats);
     return CCAL_OK;
@@ -478,6 +492,7 @@ int ccal_set_image_points(ccal_ctx *c, const float *img_host) {
     c->d_img = c->d_img_own;
     c->have_img = true;
     c->have_H = false;
+    drop_pending_focal(c);
     c->have_result = false;
     return CCAL_OK;
 }
@@ -496,6 +511,7 @@ int ccal_set_image_points_device(ccal_ctx *c, const float *img_device) {
     c->d_img = img_device;
     c->have_img = true;
     c->have_H = false;                 // (the same pointer may hold other corners now)
+    drop_pending_focal(c);
     c->have_result = false;
     return CCAL_OK;
 }
@@ -508,6 +524,7 @@ int ccal_set_intrinsics(ccal_ctx *c, const double intr[CCAL_NINTR]) {
     if (!(intr[0] > 0 && intr[1] > 0)) return fail(CCAL_E_ARG, "ccal_set_intrinsics: focal lengths must be > 0");
     memcpy(c->intr0, intr, sizeof c->intr0);
     c->intr_distorted = false;
+    drop_pending_focal(c);
     for (int a = 4; a < CCAL_NINTR; a++) c->intr_distorted = c->intr_distorted || intr[a] != 0.0;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_intr0, c->intr0, sizeof c->intr0, hipMemcpyHostToDevice, c->stream));
@@ -621,6 +638,11 @@ static bool init_spec(const ccal_ctx *c) {
     return ng <= (int64_t)init_simd_count();
 }
 
+// Not absurdly many images on this GPU: its share of the focal least squares is summed exactly by k_init_homography itself
+// (single GPU: solved from those sums; image-sharded: the decoded sums are what the ranks add up -- one rank reproduces the
+// single-GPU bits)
+static bool focal_exact(const ccal_ctx *c) { return c->N <= LM_FOC_MAX_IMAGES; }
+
 // A4 in two halves, so that shards sharing one in-order stream (p2p_split) can put every shard's send in front
 // of every shard's receive:  a = homographies + local focal sums (+ send),  b = (receive | all-reduce) + 2x2 solve
 static int init_intrinsics_a(ccal_ctx *c) {
@@ -630,11 +652,28 @@ static int init_intrinsics_a(ccal_ctx *c) {
         return fail(CCAL_E_NONPLANAR, "For non-planar calibration rigs the initial intrinsic matrix must be specified");
     HIPCHK(hipSetDevice(c->device));
     c->run_t0 = now_s();
-    HIPCHK(launch_init_homography(c->stream, c->d_obj, c->d_img, c->d_H, c->d_foc_partials, c->N, c->P, c->width,
-                                  c->height, init_spec(c)));
+    // this GPU holds every image: the focal sums are formed exactly by the homography kernel itself (focal_exact)
+    long long *foc_acc = nullptr;
+    if (focal_exact(c)) {
+        if (c->focal_pending) c->foc_dirty = true;         // (a pipeline was abandoned between its two init stages)
+        c->focal_pending = false;
+        if (c->foc_dirty) {
+            HIPCHK(hipMemsetAsync(c->d_foc_acc, 0, sizeof(long long) * 2 * LM_FOC_ACC_WORDS, c->stream));
+            c->foc_dirty = false;
+            c->foc_buf = 0;
+        }
+        foc_acc = c->d_foc_acc + (size_t)c->foc_buf * LM_FOC_ACC_WORDS;
+    }
+    HIPCHK(launch_init_homography(c->stream, c->d_obj, c->d_img, c->d_H, c->d_foc_partials, foc_acc,
+                                  (foc_acc != nullptr && c->defer_sync) ? c->d_fail : nullptr, c->N, c->P, c->width, c->height, init_spec(c)));
     c->have_H = true;
     if (sharded(c)) {
-        HIPCHK(launch_init_focal_reduce(c->stream, c->d_foc_partials, c->d_foc_red, c->N));
+        if (foc_acc != nullptr) {
+            HIPCHK(launch_init_focal_acc_row(c->stream, foc_acc, c->d_foc_acc + (size_t)(c->foc_buf ^ 1) * LM_FOC_ACC_WORDS, c->d_foc_red));
+            c->foc_buf ^= 1;
+        } else {
+            HIPCHK(launch_init_focal_reduce(c->stream, c->d_foc_partials, c->d_foc_red, c->N));
+        }
         if (via_p2p(c) && c->p2p_split) HIPCHK(launch_p2p_send(c->stream, c->p2p->dev(), c->d_foc_red, NFOC));
     }
     return CCAL_OK;
@@ -644,7 +683,17 @@ static int init_intrinsics_b(ccal_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
     const double aspect = (c->flags & CCAL_FIX_ASPECT_RATIO) ? c->aspect : 0.0;
     int rc = CCAL_OK;
-    if (!sharded(c)) {
+    if (focal_exact(c) && !sharded(c)) {
+        // the sums are in the exact accumulators.  Stages as one pipeline: the pose kernel that follows solves in its prologue
+        // (no kernel here); called on its own: one small kernel.  Same sums, same arithmetic, same bits.
+        if (c->defer_sync && c->init_hmode != 0) {
+            c->focal_pending = true;
+        } else {
+            long long *cur = c->d_foc_acc + (size_t)c->foc_buf * LM_FOC_ACC_WORDS, *other = c->d_foc_acc + (size_t)(c->foc_buf ^ 1) * LM_FOC_ACC_WORDS;
+            HIPCHK(launch_init_focal_acc(c->stream, cur, other, c->d_intr0, c->d_fail, c->width, c->height, aspect));
+            c->foc_buf ^= 1;
+        }
+    } else if (!sharded(c)) {
         // this GPU holds every image: sums and the 2x2 solve in one launch
         HIPCHK(launch_init_focal_reduce_solve(c->stream, c->d_foc_partials, c->d_foc_red, c->N, c->d_intr0, c->d_fail, c->width,
                                               c->height, aspect));
@@ -680,8 +729,20 @@ int ccal_init_extrinsics(ccal_ctx *c) {
     // the pixel-space homographies of the intrinsics stage stand in for the second, normalised homography OpenCV computes
     // here whenever they exist for these corners and the intrinsics carry no distortion (k_init_extrinsics, HMODE)
     const bool use_H = c->have_H && !c->intr_distorted && c->init_hmode != 0;
+    InitFocal focal{};
+    const bool fused_focal = c->focal_pending;
+    if (fused_focal) {
+        if (!use_H) return fail(CCAL_E_STATE, "ccal_init_extrinsics: pipeline state lost between the two initialisation stages");
+        focal.acc = c->d_foc_acc + (size_t)c->foc_buf * LM_FOC_ACC_WORDS;
+        focal.acc_clear = c->d_foc_acc + (size_t)(c->foc_buf ^ 1) * LM_FOC_ACC_WORDS;
+        focal.intr0_out = c->d_intr0;
+        focal.width = c->width; focal.height = c->height;
+        focal.aspect = (c->flags & CCAL_FIX_ASPECT_RATIO) ? c->aspect : 0.0;
+        c->foc_buf ^= 1;
+        c->focal_pending = false;
+    }
     HIPCHK(launch_init_extrinsics(c->stream, c->d_obj, c->d_img, c->d_intr0, use_H ? c->d_H : nullptr, c->init_hmode, init_spec(c),
-                                  c->d_ext0, c->d_fail, c->N, c->P));
+                                  c->d_ext0, c->d_fail, c->N, c->P, fused_focal ? &focal : nullptr));
     int rc;
     if (!c->defer_sync && (rc = finish_init(c, false, true)) != CCAL_OK) return rc;
     c->stats.t_init_extr_s = now_s() - t0;

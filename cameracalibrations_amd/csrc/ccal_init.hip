@@ -16,6 +16,7 @@
 // arithmetic.  Per-image iteration counts differ, hence one wave per workgroup.
 #include <hip/hip_runtime.h>
 
+#include "ccal_acc.hpp"
 #include "ccal_kernels.hpp"
 #include "ccal_math.hpp"
 #include "ccal_state.hpp"
@@ -468,6 +469,28 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch
     return finite;
 }
 
+// ---- the focal least squares summed EXACTLY across the images of one GPU (ccal_acc.hpp's fixed-point limbs, as the LM's reduced
+//      system): k_init_homography adds its image's five sums + failure flag with integer atomics into replica (image mod 8) of
+//      [FOC_REPL][ACC_LIMBS][NFOC] int64 words; whoever needs the totals -- k_init_focal_acc, or every workgroup of the pose
+//      stage in its prologue when the stages run as one pipeline (no focal kernel, no boundary in between) -- reads the eight
+//      replicas, decodes and solves: the same bits everywhere, whatever the order the images finished in.  Two buffers rotate:
+//      the reader of one clears the other for the next fit. ----
+constexpr int FOC_REPL = 8;
+constexpr int FOC_WORDS = ACC_LIMBS * NFOC;          // 40 int64 words per replica
+static_assert(FOC_REPL * FOC_WORDS == LM_FOC_ACC_WORDS, "host-side size of one focal accumulator buffer");
+
+__device__ __forceinline__ void foc_acc_add(long long *__restrict__ rep, int col, double v) {
+    int j, flag;
+    int64_t lo, hi;
+    acc_split(v, j, lo, hi, flag);
+    if (flag) {
+        __hip_atomic_fetch_add(rep + (flag - 1) * NFOC + (NFOC - 1), 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (lo != 0) __hip_atomic_fetch_add(rep + j * NFOC + col, (long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hi != 0) __hip_atomic_fetch_add(rep + (j + 1) * NFOC + col, (long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // A4: homography per image + its two rows of the focal-length least squares
 // ---------------------------------------------------------------------------------------
@@ -475,10 +498,12 @@ __device__ bool wave_homography(const Pts &pts, int P, int lane, double *scratch
 // the polish (what k_init_extrinsics starts OpenCV's second polish from, HMODE 1)
 template <bool SPEC>
 __global__ __launch_bounds__(64) void k_init_homography(const float *__restrict__ obj, const float *__restrict__ img,
-                                                         double *__restrict__ H_out, double *__restrict__ foc, int N,
+                                                         double *__restrict__ H_out, double *__restrict__ foc,
+                                                         long long *__restrict__ foc_acc, int *__restrict__ fail0, int N,
                                                          int P, int width, int height) {
     __shared__ __attribute__((aligned(16))) double s_sums[sums_scratch_doubles(HSUMS)];
     const int i = blockIdx.x, lane = threadIdx.x;
+    if (fail0 != nullptr && i == 0 && lane == 0) *fail0 = 0;     // (pipeline form: no focal kernel will zero the pose stage's failure counter)
     const RawPoints raw{obj, reinterpret_cast<const float2 *>(img) + (size_t)i * P};
     CachedPoints<RawPoints> pts;
     pts.init(raw, lane, P);
@@ -520,14 +545,15 @@ __global__ __launch_bounds__(64) void k_init_homography(const float *__restrict_
 #pragma unroll
         for (int k = 1; k < NFOC; k++) v = (lane == k) ? out[k] : v;
         foc[(size_t)NFOC * i + lane] = v;
+        // this GPU holds every image: the sums are formed right here, exactly (see foc_acc_add)
+        if (foc_acc != nullptr && lane < NFOC - 2) foc_acc_add(foc_acc + (i & (FOC_REPL - 1)) * FOC_WORDS, lane, v);
     }
 }
 
 // [OCV-K cvInitIntrinsicParams2D]: cvSolve(A, b, f, CV_NORMAL + CV_SVD) on the 2x2 normal equations (one thread)
-__device__ void focal_solve(const double *red, double *__restrict__ intr0, int *__restrict__ fail_count, int width, int height,
-                            double aspect) {
+__device__ __forceinline__ void focal_from_sums(const double *red, int width, int height, double aspect, double intr[NINTR], int &bad) {
     double A[3] = {red[0], red[1], red[2]}, f[2] = {red[3], red[4]};
-    int bad = red[5] > 0.0 ? 1 : 0;
+    bad = red[5] > 0.0 ? 1 : 0;
     double ip2[2];
     if (chol_packed<2>(A, ip2)) {
         fwd_subst<2>(A, ip2, f);
@@ -541,13 +567,64 @@ __device__ void focal_solve(const double *red, double *__restrict__ intr0, int *
         fx = aspect * tf;
         fy = tf;
     }
-    intr0[0] = fx;
-    intr0[1] = fy;
-    intr0[2] = !width ? 0.5 : (width - 1) * 0.5;
-    intr0[3] = !height ? 0.5 : (height - 1) * 0.5;
-    for (int a = 4; a < 9; a++) intr0[a] = 0.0;
+    intr[0] = fx;
+    intr[1] = fy;
+    intr[2] = !width ? 0.5 : (width - 1) * 0.5;
+    intr[3] = !height ? 0.5 : (height - 1) * 0.5;
+#pragma unroll
+    for (int a = 4; a < NINTR; a++) intr[a] = 0.0;
+}
+
+__device__ void focal_solve(const double *red, double *__restrict__ intr0, int *__restrict__ fail_count, int width, int height,
+                            double aspect) {
+    double intr[NINTR];
+    int bad;
+    focal_from_sums(red, width, height, aspect, intr, bad);
+    for (int a = 0; a < NINTR; a++) intr0[a] = intr[a];
     fail_count[1] = bad;
     fail_count[0] = 0;                 // the pose stage that follows counts its failed views here
+}
+
+// one wave: the totals of one buffer -> s_red[NFOC] (LDS); s_part: FOC_WORDS AccPart of LDS scratch.  A NaN / out-of-range
+// contribution anywhere turns the sums into NaN (the solve then reports a failed focal estimate).
+__device__ __forceinline__ void foc_acc_read(const long long *__restrict__ acc, AccPart *s_part, double *s_red, int lane) {
+    if (lane < FOC_WORDS) {
+        long long t = 0;
+#pragma unroll
+        for (int r = 0; r < FOC_REPL; r++) t += acc[r * FOC_WORDS + lane];
+        AccPart p;
+        p.hi = p.lo = 0.0;
+        acc_part_add(p, t);
+        s_part[lane] = p;
+    }
+    wave_lds_sync();
+    if (lane < NFOC) {
+        AccPart part[ACC_LIMBS];
+#pragma unroll
+        for (int j = 0; j < ACC_LIMBS; j++) part[j] = s_part[j * NFOC + lane];
+        double v = acc_decode(part);
+        const AccPart n_nan = s_part[0 * NFOC + NFOC - 1], n_big = s_part[1 * NFOC + NFOC - 1];
+        if (lane >= NFOC - 2) v = 0.0;                // (the two pad columns carry no value; the last one carries the flags)
+        if (n_nan.hi != 0.0 || n_nan.lo != 0.0 || n_big.hi != 0.0 || n_big.lo != 0.0) v = __longlong_as_double(0x7ff8000000000000ll);
+        s_red[lane] = v;
+    }
+    wave_lds_sync();
+}
+
+// red_out != NULL: an image-sharded fit -- this rank's sums go out as NFOC doubles (summed across the ranks before the solve)
+__global__ __launch_bounds__(64) void k_init_focal_acc(const long long *__restrict__ acc, long long *__restrict__ acc_clear,
+                                                        double *__restrict__ red_out, double *__restrict__ intr0,
+                                                        int *__restrict__ fail_count, int width, int height, double aspect) {
+    __shared__ AccPart s_part[FOC_WORDS];
+    __shared__ double s_red[NFOC];
+    const int lane = threadIdx.x;
+    foc_acc_read(acc, s_part, s_red, lane);
+    if (red_out != nullptr) {
+        if (lane < NFOC) red_out[lane] = s_red[lane];
+    } else if (lane == 0) {
+        focal_solve(s_red, intr0, fail_count, width, height, aspect);
+    }
+    for (int k = lane; k < FOC_REPL * FOC_WORDS; k += 64) acc_clear[k] = 0;
 }
 
 // intr0 != NULL: this GPU holds every image, the solve follows in the same launch (no all-reduce in between)
@@ -704,11 +781,21 @@ __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int
 //      the same optimum (1e-11); a view that exhausts CvLevMarq's 20 iterations ends where 20 iterations take it from the
 //      slightly different start -- opt-in (ccal_set_pose_init), not OpenCV's trajectory for such views
 // LDSP = the normalised correspondences are staged in LDS (32 P bytes); false: read through NormPoints (any P).
-template <bool SPEC, int HMODE, bool LDSP>
+// FOC: the stages run as one pipeline on a GPU that holds every image -- the initial intrinsics do not exist yet: every
+// workgroup reads the exact focal sums k_init_homography has just formed (FocalArgs), solves the 2 x 2 system itself (the same bits
+// in all of them) and workgroup 0 stores the intrinsics for the LM and clears the other accumulator buffer.
+struct FocalArgs {
+    const long long *acc;        // this fit's accumulator buffer
+    long long *acc_clear;        // the other one, cleared for the next fit
+    double *intr0_out;
+    int width, height;
+    double aspect;
+};
+template <bool SPEC, int HMODE, bool LDSP, bool FOC = false>
 __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const float *__restrict__ obj, const float *__restrict__ img,
                                                          const double *__restrict__ intr0, const double *__restrict__ H_pix,
                                                          double *__restrict__ ext,
-                                                         int *__restrict__ fail_count, int N, int P) {
+                                                         int *__restrict__ fail_count, int N, int P, const FocalArgs F) {
     __shared__ __attribute__((aligned(16))) double s_sums[sums_scratch_doubles(HSUMS)];
     const int i = blockIdx.x, lane = threadIdx.x;
     const float2 *img_i = reinterpret_cast<const float2 *>(img) + (size_t)i * P;
@@ -717,10 +804,33 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
     pts.obj = obj;
     pts.img = img_i;
     bool distorted = false;
+    if constexpr (FOC) {
+        static_assert(HMODE != 0, "the fused focal solve belongs to the pipeline, where the homographies exist");
+        AccPart *s_part = reinterpret_cast<AccPart *>(s_sums);            // (the sums scratch is not in use yet)
+        double *s_red = s_sums + 2 * FOC_WORDS;
+        foc_acc_read(F.acc, s_part, s_red, lane);
+        double red[NFOC];
+#pragma unroll
+        for (int k = 0; k < NFOC; k++) red[k] = s_red[k];
+        int bad;
+        focal_from_sums(red, F.width, F.height, F.aspect, pts.in, bad);
+        wave_lds_sync();
+        if (i == 0) {
+            if (lane < NINTR) {
+                double v = pts.in[0];
+#pragma unroll
+                for (int a = 1; a < NINTR; a++) v = (lane == a) ? pts.in[a] : v;
+                F.intr0_out[lane] = v;
+            }
+            if (lane == 0) fail_count[1] = bad;
+            for (int k = lane; k < FOC_REPL * FOC_WORDS; k += 64) F.acc_clear[k] = 0;
+        }
+    } else {
 #pragma unroll
     for (int a = 0; a < NINTR; a++) {
         pts.in[a] = intr0[a];
         if (a >= 4 && pts.in[a] != 0.0) distorted = true;
+    }
     }
     pts.distorted = distorted;
     // template centroid (R_transform = I for a z = 0 board: T_transform = -Mc)
@@ -952,13 +1062,22 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
 
 // ---------------------------------------------------------------------------------------
 hipError_t launch_init_homography(hipStream_t stream, const float *obj, const float *img, double *H_out,
-                                  double *foc_partials, int N, int P, int width, int height, bool spec) {
+                                  double *foc_partials, long long *foc_acc, int *fail0, int N, int P, int width, int height, bool spec) {
     // up to one image per SIMD the launch is as long as its slowest image: trial points by the normal-equations pass;
     // beyond that it is throughput: the leaner form that keeps two waves per SIMD
     if (spec)
-        hipLaunchKernelGGL(k_init_homography<true>, dim3(N), dim3(64), 0, stream, obj, img, H_out, foc_partials, N, P, width, height);
+        hipLaunchKernelGGL(k_init_homography<true>, dim3(N), dim3(64), 0, stream, obj, img, H_out, foc_partials, foc_acc, fail0, N, P, width, height);
     else
-        hipLaunchKernelGGL(k_init_homography<false>, dim3(N), dim3(64), 0, stream, obj, img, H_out, foc_partials, N, P, width, height);
+        hipLaunchKernelGGL(k_init_homography<false>, dim3(N), dim3(64), 0, stream, obj, img, H_out, foc_partials, foc_acc, fail0, N, P, width, height);
+    return hipGetLastError();
+}
+hipError_t launch_init_focal_acc(hipStream_t stream, const long long *acc, long long *acc_clear, double *intr0, int *fail_count,
+                                 int width, int height, double aspect) {
+    hipLaunchKernelGGL(k_init_focal_acc, dim3(1), dim3(64), 0, stream, acc, acc_clear, (double *)nullptr, intr0, fail_count, width, height, aspect);
+    return hipGetLastError();
+}
+hipError_t launch_init_focal_acc_row(hipStream_t stream, const long long *acc, long long *acc_clear, double *red_out) {
+    hipLaunchKernelGGL(k_init_focal_acc, dim3(1), dim3(64), 0, stream, acc, acc_clear, red_out, (double *)nullptr, (int *)nullptr, 0, 0, 0.0);
     return hipGetLastError();
 }
 hipError_t launch_init_focal_reduce(hipStream_t stream, const double *foc_partials, double *foc_red, int N) {
@@ -993,17 +1112,32 @@ int init_simd_count() {
 }
 
 hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const float *img, const double *intr0, const double *H_pix,
-                                  int hmode, bool spec, double *ext, int *fail_count, int N, int P) {
+                                  int hmode, bool spec, double *ext, int *fail_count, int N, int P, const InitFocal *focal) {
     // the staged correspondences (32 P bytes) next to the static scratch must fit a workgroup's 64 KB of LDS; bigger boards
     // read them through NormPoints (lean form only: that instantiation exists for throughput anyway)
     const size_t lds_pts = sizeof(double) * 4 * (size_t)P;
     const bool ldsp = lds_pts + sizeof(double) * sums_scratch_doubles(HSUMS) + 256 <= 64 * 1024;
     if (H_pix == nullptr) hmode = 0;
     if (!ldsp) spec = false;
+    FocalArgs F{};
+    const bool foc = focal != nullptr;
+    if (foc) {
+        if (hmode == 0) return hipErrorInvalidValue;      // (the pipeline form needs the intrinsics stage's homographies)
+        F.acc = focal->acc; F.acc_clear = focal->acc_clear; F.intr0_out = focal->intr0_out;
+        F.width = focal->width; F.height = focal->height; F.aspect = focal->aspect;
+    }
     auto go = [&](auto kernel, size_t dyn) {
-        hipLaunchKernelGGL(kernel, dim3(N), dim3(64), dyn, stream, obj, img, intr0, H_pix, ext, fail_count, N, P);
+        hipLaunchKernelGGL(kernel, dim3(N), dim3(64), dyn, stream, obj, img, intr0, H_pix, ext, fail_count, N, P, F);
     };
-    if (hmode == 2) {                       // no pass over normalised points at all
+    if (foc) {                              // stages as one pipeline: the focal solve in the prologue
+        if (hmode == 2) {
+            if (spec) go(k_init_extrinsics<true, 2, true, true>, 0); else go(k_init_extrinsics<false, 2, true, true>, 0);
+        } else {
+            if (!ldsp) go(k_init_extrinsics<false, 1, false, true>, 0);
+            else if (spec) go(k_init_extrinsics<true, 1, true, true>, lds_pts);
+            else go(k_init_extrinsics<false, 1, true, true>, lds_pts);
+        }
+    } else if (hmode == 2) {                // no pass over normalised points at all
         if (spec) go(k_init_extrinsics<true, 2, true>, 0); else go(k_init_extrinsics<false, 2, true>, 0);
     } else if (hmode == 1) {
         if (!ldsp) go(k_init_extrinsics<false, 1, false>, 0);

@@ -56,8 +56,24 @@ hipError_t launch_lm_recv(hipStream_t stream, const LmState *st, double *out, co
 // ccal_init.hip -- closed-form initialisation
 constexpr int NFOC = 8;   // doubles all-reduced for the focal least squares: AtA(3) Atb(2) fail(1) pad(2)
 int init_simd_count();          // SIMDs of the current device: up to one image per SIMD the init kernels run their speculative form
+constexpr int LM_FOC_ACC_WORDS = 8 * 5 * 8;   // int64 words of one buffer of exact focal sums: [8 replicas][5 limbs][NFOC]
+constexpr int LM_FOC_MAX_IMAGES = 8 * 1500;   // images per GPU whose focal sums the exact accumulators take (adds per address within the limbs' headroom)
+// foc_acc != NULL (this GPU holds every image): the kernel also adds each image's focal sums, exactly, into that buffer (zero on
+// entry); fail0 != NULL: the kernel zeroes the pose stage's failure counter (no focal kernel will)
 hipError_t launch_init_homography(hipStream_t stream, const float *obj, const float *img, double *H_out,
-                                  double *foc_partials, int N, int P, int width, int height, bool spec);
+                                  double *foc_partials, long long *foc_acc, int *fail0, int N, int P, int width, int height, bool spec);
+// the exact focal sums of `acc` -> 2 x 2 solve -> intr0, fail_count[1] (and fail_count[0] = 0); clears `acc_clear`
+hipError_t launch_init_focal_acc(hipStream_t stream, const long long *acc, long long *acc_clear, double *intr0, int *fail_count,
+                                 int width, int height, double aspect);
+// image-sharded fits: this rank's exact sums as NFOC doubles (what is summed across the ranks); clears `acc_clear`
+hipError_t launch_init_focal_acc_row(hipStream_t stream, const long long *acc, long long *acc_clear, double *red_out);
+struct InitFocal {                            // pipeline form of the pose stage: the focal solve in its prologue
+    const long long *acc;
+    long long *acc_clear;
+    double *intr0_out;
+    int width, height;
+    double aspect;
+};
 hipError_t launch_init_focal_reduce(hipStream_t stream, const double *foc_partials, double *foc_red, int N);
 hipError_t launch_init_focal_reduce_solve(hipStream_t stream, const double *foc_partials, double *foc_red, int N, double *intr0,
                                           int *fail_count, int width, int height, double aspect);
@@ -65,7 +81,7 @@ hipError_t launch_init_focal_solve(hipStream_t stream, const double *foc_red, do
                                    int width, int height, double aspect);
 // H_pix: k_init_homography's output for the same image points (NULL: none); hmode 0 / 1 / 2 see k_init_extrinsics
 hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const float *img, const double *intr0, const double *H_pix,
-                                  int hmode, bool spec, double *ext, int *fail_count, int N, int P);
+                                  int hmode, bool spec, double *ext, int *fail_count, int N, int P, const InitFocal *focal = nullptr);
 
 // ccal_maps.hip -- RowCol <-> XYZ maps and the four RMS metrics
 struct MapIntr { double f[2], c[2], k, cs; };   // intrinsic map parameters + checker_size, a kernel argument by value
