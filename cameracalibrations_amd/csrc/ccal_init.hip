@@ -814,6 +814,14 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
         for (int k = 0; k < NFOC; k++) red[k] = s_red[k];
         int bad;
         focal_from_sums(red, F.width, F.height, F.aspect, pts.in, bad);
+        // From here on the kernel must compile to what the stage-by-stage form (intrinsics loaded from memory) compiles to, so that
+        // the pipeline and the stages give the same bits: the values are made opaque (the five zeros of the distortion would
+        // otherwise be folded into the rows' arithmetic, which changes which products the compiler fuses).
+#pragma unroll
+        for (int a = 0; a < NINTR; a++) {
+            asm volatile("" : "+v"(pts.in[a]));
+            if (a >= 4 && pts.in[a] != 0.0) distorted = true;
+        }
         wave_lds_sync();
         if (i == 0) {
             if (lane < NINTR) {

@@ -1198,3 +1198,26 @@ def test_split_images_in_a_sharded_fit():
         assert r["iters"] == base["iters"] and abs(r["rms"] - base["rms"]) < 1e-12
         assert np.abs(r["rvecs"] - base["rvecs"]).max() < 1e-9 and np.abs(r["tvecs"] - base["tvecs"]).max() < 1e-8
         _ffi.lib().ccal_thread_cleanup()
+
+
+@pytest.mark.parametrize("name,n", [("C3", 300), ("C5", 1100), ("REF", 9)])
+def test_one_pipeline_fit_equals_the_stages_bit_for_bit(name, n):
+    """`ccal_fit` (the stages enqueued as one pipeline: the focal 2 x 2 solve runs in the pose kernel's prologue, the init's flags
+    travel with the first LM launch) against the same stages called one by one (their own focal kernel, the read-back kernel):
+    same initial values and same fit, bit for bit -- in the latency form of the init kernels (300 / 9 images) and in the throughput
+    form (1100 images, more than the chip has SIMDs), whose pose kernel once compiled to other bits with the intrinsics known to
+    the compiler."""
+    wl = syn.named_workload(name, n_images=n)
+    with _solver(wl, REF) as s:
+        s.init_intrinsics()
+        s.init_extrinsics()
+        i_st, rt_st = s.get_init()
+        s.lm_run()
+        r_st = s.result()
+        s.fit()
+        i_pl, rt_pl = s.get_init()
+        r_pl = s.result()
+    assert np.array_equal(i_st, i_pl) and np.array_equal(rt_st, rt_pl)
+    assert r_st["rms"] == r_pl["rms"] and r_st["iters"] == r_pl["iters"]
+    for k in ("intr", "rvecs", "tvecs"):
+        assert np.array_equal(r_st[k], r_pl[k]), k
