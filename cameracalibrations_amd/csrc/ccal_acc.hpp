@@ -52,14 +52,22 @@ CCAL_ACC_HD void acc_split(double x, int &j, int64_t &lo, int64_t &hi, int &flag
     hi = bits < 0 ? -h : h;
 }
 
-// One limb's total over the replicas (added as int64 by the reader: at most 1024 adds of 52-bit payloads, no
-// overflow) as two binary64 halves: a == (a >> 32) * 2^32 + (a & 0xffffffff) for two's-complement a, both halves
+// One limb's total as two binary64 halves (an address takes at most ACC_MAX_ADDS adds of 52-bit payloads: no int64
+// overflow per replica; the replicas are added up in this form, where nothing can overflow): a == (a >> 32) * 2^32 + (a & 0xffffffff) for two's-complement a, both halves
 // convert exactly (one v_cvt each on the device).  From here on the decode is floating point: no 64-bit integer
 // carry chain, which gfx950 would have to emulate with two 32-bit instructions per operation.
 struct AccPart { double hi, lo; };
 CCAL_ACC_HD void acc_part_add(AccPart &p, int64_t a) {
     p.hi += (double)(int32_t)(a >> 32);
     p.lo += (double)(uint32_t)((uint64_t)a & 0xffffffffull);
+}
+
+// canonical form of a sum of several acc_part_add()s: 0 <= lo < 2^32, same total (all exact while |total| < 2^84), so that
+// what acc_decode() makes of the parts is a function of the TOTAL alone, not of how it was spread over replicas
+CCAL_ACC_HD void acc_part_norm(AccPart &p) {
+    const double c = floor(p.lo * 0x1p-32);
+    p.hi += c;
+    p.lo -= c * 0x1p32;
 }
 
 // limbs (as AccPart sums) -> double: value = sum_j (hi_j 2^32 + lo_j) 2^(52 j - 150), added from the top limb

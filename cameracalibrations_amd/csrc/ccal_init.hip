@@ -589,12 +589,14 @@ __device__ void focal_solve(const double *red, double *__restrict__ intr0, int *
 // contribution anywhere turns the sums into NaN (the solve then reports a failed focal estimate).
 __device__ __forceinline__ void foc_acc_read(const long long *__restrict__ acc, AccPart *s_part, double *s_red, int lane) {
     if (lane < FOC_WORDS) {
-        long long t = 0;
-#pragma unroll
-        for (int r = 0; r < FOC_REPL; r++) t += acc[r * FOC_WORDS + lane];
+        // every replica is split on its own: one address takes up to N / FOC_REPL adds of 52-bit payloads (< 2^63 for
+        // N <= LM_FOC_MAX_IMAGES), but the total over the replicas would not fit an int64 beyond ~4096 images; the binary64
+        // halves stay below 2^36 in magnitude, so their sums are exact
         AccPart p;
         p.hi = p.lo = 0.0;
-        acc_part_add(p, t);
+#pragma unroll
+        for (int r = 0; r < FOC_REPL; r++) acc_part_add(p, acc[r * FOC_WORDS + lane]);
+        acc_part_norm(p);
         s_part[lane] = p;
     }
     wave_lds_sync();

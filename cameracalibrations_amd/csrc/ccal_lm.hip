@@ -369,7 +369,7 @@ static_assert(ACC_ROW % 2 == 0, "replicas are read as 16-byte pairs");
 
 // Reading the exact accumulators (ccal_acc.hpp) of one trial: thread t < 170 owns the 16-byte pair t of
 // every replica; all loads are issued before anything waits on memory (one round trip), the replicas are
-// added as split integer sums (no overflow for any grid size) and left in LDS for acc_row_decode().
+// added as split sums (no overflow for any grid size) and left in LDS for acc_row_decode().
 struct AccRegs { longlong2 v[8]; };                // the first eight replicas' pair, requested before anything waits
 
 // issue only: no arithmetic between these loads and the other loads of the prologue
@@ -379,15 +379,16 @@ __device__ __forceinline__ void acc_read_issue(const long long *__restrict__ acc
     for (int r = 0; r < 8; r++) q.v[r] = (tid < ACC_PAIRS && r < R) ? src[(size_t)r * ACC_PAIRS] : make_longlong2(0, 0);
 }
 
-// Replica sums -> LDS.  The replicas are added as 64-bit integers (a limb holds 52 payload bits and an address
-// receives at most grid / R adds, the grid is capped at 1024 workgroups: the sum over all replicas stays below
-// 2^62), then split ONCE into the two exactly representable halves acc_decode() takes.
+// Replica sums -> LDS.  Every replica's word is split on its own into the two exactly representable halves acc_decode()
+// takes and the halves are added as doubles: one address receives at most ACC_MAX_ADDS adds of 52-bit payloads (no int64
+// overflow per replica), while the total over all replicas of a grid of more than 2^11 workgroups would not fit an int64.
 template <bool SC1 = false>
 __device__ __forceinline__ void acc_read_stage(const long long *__restrict__ acc, int R, AccPart *s_acc, int tid, const AccRegs &q) {
     if (tid >= ACC_PAIRS) return;
-    long long t0 = 0, t1 = 0;
+    AccPart p0, p1;
+    p0.hi = p0.lo = p1.hi = p1.lo = 0.0;
 #pragma unroll
-    for (int r = 0; r < 8; r++) { t0 += q.v[r].x; t1 += q.v[r].y; }
+    for (int r = 0; r < 8; r++) { acc_part_add(p0, q.v[r].x); acc_part_add(p1, q.v[r].y); }
     const longlong2 *src = reinterpret_cast<const longlong2 *>(acc) + tid;
     for (int r0 = 8; r0 < R; r0 += 8) {             // more than eight replicas (very large grids only)
         longlong2 v[8];
@@ -401,12 +402,10 @@ __device__ __forceinline__ void acc_read_stage(const long long *__restrict__ acc
             } else v[r] = src[(size_t)(r0 + r) * ACC_PAIRS];
         }
 #pragma unroll
-        for (int r = 0; r < 8; r++) { t0 += v[r].x; t1 += v[r].y; }
+        for (int r = 0; r < 8; r++) { acc_part_add(p0, v[r].x); acc_part_add(p1, v[r].y); }
     }
-    AccPart p0, p1;
-    p0.hi = p0.lo = p1.hi = p1.lo = 0.0;
-    acc_part_add(p0, t0);
-    acc_part_add(p1, t1);
+    acc_part_norm(p0);
+    acc_part_norm(p1);
     s_acc[2 * tid] = p0;
     s_acc[2 * tid + 1] = p1;
 }
@@ -568,6 +567,10 @@ __device__ void lm_boot(LmState *ls, const LmInit &init, const double *intr0, in
 // the LM advance the prologue stores the row into the peers' inboxes (workgroup 0) and adds the
 // peers' rows from the local inbox in rank order (every workgroup) -- the whole all-reduce, with
 // no launch of its own.  The first launch of a solve takes the next sequence number.
+// The wave-uniform operands of the rows (R, K, t, the intrinsics: 39 doubles) in scalar registers instead of 78 vector registers
+#ifndef CCAL_SGPR_UNIFORMS
+#define CCAL_SGPR_UNIFORMS 0
+#endif
 #ifndef CCAL_TRIAL_MIN_WAVES
 #define CCAL_TRIAL_MIN_WAVES 2   /* two workgroups per CU (LDS-limited anyway): keep the register file share of two waves per SIMD */
 #endif
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     {
         const double *src = (mode == MODE_EVAL) ? ls.intr_cand : ls.intr_prev;
 #pragma unroll
-        for (int a = 0; a < NINTR; a++) in[a] = src[a];
+        for (int a = 0; a < NINTR; a++) in[a] = CCAL_SGPR_UNIFORMS ? to_sgpr(src[a]) : src[a];
     }
     auto bcast = [](double v, int src) -> double {
         return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src),
@@ -867,7 +870,11 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
 #pragma unroll
     for (int k = 0; k < 6; k++) e6[k] = bcast(hselb, BLK_EXT - 64 + k);
     double dnum = 0.0, dden = 0.0;
+#ifdef CCAL_EXP_SKIP_A             // timing experiment only (wrong results): what pose update + rotation cost a launch
+    if (false) {
+#else
     if (mode == MODE_EVAL) {
+#endif
         // delta_i = C_l^-1 (h - B^T delta_int) = u_h - U_B delta_int, U kept by the last sweep one value per
         // lane: lane 16 k + j multiplies U[j][k] by (-delta_int[j] | +1 for j = 9 | 0), a DPP sum inside each row
         // of 16 lanes leaves component k in row k (k = 0..3: first block word; k = 4, 5: second one)
@@ -890,7 +897,19 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     // ---- 3. rows -> LDS -> f64 MFMA Gram ----
     STAMP(2);
     double R[9], K[9];
+#ifdef CCAL_EXP_SKIP_A
+#pragma unroll
+    for (int q_ = 0; q_ < 9; q_++) { R[q_] = (q_ % 4 == 0) ? 1.0 : e6[q_ % 3] * 1e-3; K[q_] = R[q_]; }
+#else
     rodrigues_RK(e6, R, K);
+#endif
+    double tv[3] = {e6[3], e6[4], e6[5]};
+    if (CCAL_SGPR_UNIFORMS) {
+#pragma unroll
+        for (int q_ = 0; q_ < 9; q_++) { R[q_] = to_sgpr(R[q_]); K[q_] = to_sgpr(K[q_]); }
+#pragma unroll
+        for (int q_ = 0; q_ < 3; q_++) tv[q_] = to_sgpr(tv[q_]);
+    }
     STAMP(3);
     d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     for (int c0 = cbeg; c0 < cend; c0 += 64) {
@@ -903,13 +922,13 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         }
         const double M[3] = {(double)m0, (double)m1, (double)m2};
         double mu[NCOL], mv[NCOL];
-        point_rows_K(M, (double)uv.x, (double)uv.y, R, K, e6 + 3, in, aspect, mu, mv, valid ? 1.0 : 0.0);
+        point_rows_K(M, (double)uv.x, (double)uv.y, R, K, tv, in, aspect, mu, mv, valid ? 1.0 : 0.0);
         STAMP(4);
 #ifdef CCAL_HALF_TILE
         // half-size tile (occupancy): lanes 0..31 stage their rows, Gram of those corners, then lanes 32..63
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const int n_h = min(32, P - c0 - 32 * h);
+            const int n_h = min(32, cend - c0 - 32 * h);
             if (n_h > 0) {
                 if ((lane >> 5) == h) tile_store_rows_masked(W, lane, mu, mv);
                 wave_lds_sync();
@@ -956,7 +975,11 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     // lane j < 10 owns column j of [B^T | h]
     const int yj = lane < 10 ? lane : 9;
     double y[6];
+#ifdef CCAL_EXP_SKIP_C             // timing experiment only (wrong results): what the 6 x 6 factor and the Schur outputs cost a launch
+    if (work && A.k > 1000) {
+#else
     if (work) {
+#endif
 #pragma unroll
     for (int a = 0; a < 6; a++)
 #pragma unroll
@@ -1033,7 +1056,11 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     STAMP(9);
 
     // ---- U = L^-T Y and this image's block for the next sweep's back-substitution ----
+#ifdef CCAL_EXP_SKIP_C
+    if (work && A.k > 1000) {
+#else
     if (work) {
+#endif
     bwd_subst<6>(C, inv, y);
     Hs[lane] = 0.0;                               // (the DS unit keeps one wave's writes in order)
     Hs[64 + lane] = 0.0;
@@ -1294,6 +1321,7 @@ int lm_waves_per_image(int N, int P, bool fused) {
 
 // Workgroups of k_lm_trial the current device keeps resident (occupancy query x compute units; CCAL_MAX_GRID
 // overrides).  Both instantiations use the same resources up to a few SGPRs.
+constexpr int LM_GRID_LIMIT = 8192;   // (ACC_MAX_ADDS adds per address with up to ACC_MAX_REPLICAS replicas would allow far more)
 int lm_max_grid() {
     static int cached[16] = {0};
     int dev = 0;
@@ -1302,12 +1330,12 @@ int lm_max_grid() {
     int per_cu = 0, cus = 0;
     if (const char *e = getenv("CCAL_MAX_GRID")) {
         const int v = atoi(e);
-        if (v > 0) return cached[dev] = std::min(v, 1024);
+        if (v > 0) return cached[dev] = std::min(v, LM_GRID_LIMIT);
     }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lm_trial<FLOW_PRO_XCHG, true, 1>, WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     (void)hipGetLastError();
-    return cached[dev] = std::min(per_cu * cus, 1024);   // (1024: the accumulator replicas are summed in int64)
+    return cached[dev] = std::min(per_cu * cus, LM_GRID_LIMIT);
 }
 
 hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {

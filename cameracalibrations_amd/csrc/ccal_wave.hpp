@@ -53,6 +53,13 @@ __device__ __forceinline__ double row_bcast16(double v) {
     return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xF, 0xF, true);   // one v_mov_b64_dpp
 }
 
+// A wave-uniform double moved to a scalar register pair (two v_readfirstlane_b32).  FP64 arithmetic is vector-only on gfx950, so
+// values every lane computes alike (rotation, pose, intrinsics) live in VGPRs unless they are moved by hand; as VOP3 operands they
+// cost nothing from there (one scalar source per instruction), and 39 of them are 78 vector registers returned to the rows.
+__device__ __forceinline__ double to_sgpr(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 // Sum inside each row of 16 lanes (lanes 16 r .. 16 r + 15), same value in every lane of the row.
 __device__ __forceinline__ double row_sum16(double v) {
     v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]

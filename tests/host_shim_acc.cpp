@@ -51,14 +51,13 @@ double shim_sum(const double *xs, int n, int R, int *flags_out) {
         acc[i % R][j] += lo;
         if (hi) acc[i % R][j + 1] += hi;
     }
-    // as the kernels read them back: replicas added as int64 (the grid is capped at 1024 workgroups, so the total
-    // number of adds per column is), then split once into the two exactly representable halves
+    // as the kernels read them back: every replica's word split into its two exactly representable halves, the halves added
+    // as doubles and brought to canonical form (csrc/ccal_lm.hip acc_read_stage, csrc/ccal_init.hip foc_acc_read)
     AccPart part[ACC_LIMBS];
     for (int j = 0; j < ACC_LIMBS; j++) {
-        int64_t t = 0;
-        for (int r = 0; r < R; r++) t += acc[r][j];
         part[j].hi = part[j].lo = 0.0;
-        acc_part_add(part[j], t);
+        for (int r = 0; r < R; r++) acc_part_add(part[j], acc[r][j]);
+        acc_part_norm(part[j]);
     }
     return acc_decode(part);
 }

@@ -103,6 +103,23 @@ def test_many_adds_do_not_overflow(shim):
     assert abs(Fraction(v) - exact(xs)) <= Fraction(ulp(v))
 
 
+@pytest.mark.parametrize("n", [4096, 6000, 12000])
+def test_replica_totals_beyond_an_int64(shim, n):
+    # The focal sums of the initialisation take one add per image (up to LM_FOC_MAX_IMAGES = 12000 on one GPU) and a sweep grid of
+    # more than 2^11 workgroups one per workgroup: all of one sign, low limbs near 2^52 each, the total over the 8 replicas is
+    # past 2^63 from ~4096 adds on.  The readers split every replica on its own (round 4 added them up as one int64 first and
+    # came out wrong by 2^64 limb units at 6000 and 12000 adds -- advisor's finding).
+    rng = np.random.default_rng(n)
+    xs = rng.uniform(0.75, 1.0, n) * 2.0 ** -99          # mantissas fill limb 0's 52 payload bits
+    v, flags = acc_sum(shim, xs, 8)
+    assert flags == (0, 0)
+    assert abs(Fraction(v) - exact(xs)) <= 2 * Fraction(ulp(v))
+    assert acc_sum(shim, xs, 64)[0] == v and acc_sum(shim, rng.permutation(xs), 8)[0] == v
+    xs = rng.uniform(0.5, 1.0, n) * 2.3e5                # magnitudes of the AtA diagonal of the focal least squares
+    v, _ = acc_sum(shim, xs, 8)
+    assert abs(Fraction(v) - exact(xs)) <= Fraction(ulp(v))
+
+
 def test_flags(shim):
     v, flags = acc_sum(shim, [1.0, float("nan"), 2.0, float("inf"), 1e40, 3.0])
     assert flags == (1, 2) and v == 6.0

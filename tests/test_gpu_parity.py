@@ -826,6 +826,23 @@ def test_c5_single_gpu_matches_oracle_full_size():
     _check_against_oracle(r, ro)
 
 
+def test_exact_focal_sums_at_ten_thousand_images():
+    """Row A4 at BASELINE.json configs[4]'s size: the focal least squares summed in the exact accumulators over 10000 images
+    (up to 1250 adds per address; the total over the eight replicas is past an int64 from ~4096 images on, which the reader of
+    round 4 did not survive) against the oracle's initial intrinsics -- an independent reference for the totals -- and the
+    fit's one-pipeline form (solve in the pose kernel's prologue) against the stage-by-stage form, bit for bit."""
+    wl = syn.named_workload("C5")
+    K4, _ = orc.init_intrinsics(wl.obj, wl.img, *wl.image_size, aspect=wl.aspect if wl.flags & 2 else 0.0)
+    with _solver(wl, REF) as s:
+        s.init_intrinsics()
+        gi, _ = s.get_init(extrinsics=False)
+        assert np.abs(gi[:2] - K4[:2]).max() / K4[1] < 1e-8, (gi[:4], K4)
+        assert np.array_equal(gi[2:4], K4[2:4])
+        s.fit()
+        gp, _ = s.get_init(extrinsics=False)
+        assert np.array_equal(gp, gi)
+
+
 def test_c5_eight_shards_match_oracle():
     """BASELINE.json configs[4] as named: the 10000 x 15x10 problem in EIGHT shards of 1250 images (the per-GPU share
     at 8 MI355X; here eight shards on the test box's one GPU driven by one host thread), against the ORACLE and

@@ -18,6 +18,7 @@ ap.add_argument("--workload", default="C3")
 ap.add_argument("--images", type=int, default=None)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--tag", default="")
+ap.add_argument("--b2b-only", action="store_true", help="back-to-back first-trial launches only (timing-experiment builds whose solves do not converge)")
 a = ap.parse_args()
 wl = syn.named_workload(a.workload, n_images=a.images)
 img = torch.from_numpy(np.ascontiguousarray(wl.img)).to("cuda:0")
@@ -26,6 +27,10 @@ s.set_problem(wl.obj, wl.n_images, wl.image_size, aspect=wl.aspect, flags=wl.fla
 s.set_image_points(img)
 s.init_intrinsics()
 s.init_extrinsics()
+if a.b2b_only:
+    s.time_sweep(50)
+    print(f"[probe {a.tag}] {wl.name} N={wl.n_images}: b2b first-trial {s.time_sweep(200):.2f} us {s.time_sweep(200):.2f} us")
+    sys.exit(0)
 for _ in range(20):
     s.lm_run()
 torch.cuda.synchronize()
