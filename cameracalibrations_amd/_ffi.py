@@ -39,7 +39,7 @@ class Stats(C.Structure):
     _fields_ = [("rms", C.c_double), ("final_err", C.c_double), ("rel_step", C.c_double),
                 ("t_init_intr_s", C.c_double), ("t_init_extr_s", C.c_double), ("t_lm_s", C.c_double),
                 ("iters", C.c_int32), ("sweeps", C.c_int32), ("reschur", C.c_int32), ("rejected", C.c_int32),
-                ("lambda_lg10", C.c_int32), ("n_bad", C.c_int32), ("timed_sweeps", C.c_int32), ("pad_", C.c_int32),
+                ("lambda_lg10", C.c_int32), ("n_bad", C.c_int32), ("timed_sweeps", C.c_int32), ("sweep_form", C.c_int32),
                 ("sweep_us", C.c_double), ("solve_kernels_us", C.c_double)]
 
     def asdict(self):

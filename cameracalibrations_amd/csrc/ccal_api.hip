@@ -34,8 +34,6 @@ namespace ccal { hipError_t debug_read_stamps(unsigned long long *out); hipError
 static constexpr int FUSED_XCHG_MAX_BLOCKS = 320;
 
 static constexpr size_t ACC_BYTES = sizeof(long long) * ACC_BUFS * ACC_MAX_REPLICAS * ACC_ROW;
-// the "workgroup done" counters of the tail-advance flow sit behind the accumulators: one memset zeroes both
-static constexpr size_t TAIL_BYTES = sizeof(unsigned int) * LM_TAIL_COUNTERS;
 
 static thread_local std::string g_err;
 
@@ -123,15 +121,16 @@ struct ccal_ctx {
     hipGraphExec_t g_first = nullptr;
     struct GraphKey {             // everything baked into the captured launches
         const void *obj, *img, *blk, *st, *acc, *red, *trace, *intr0, *ext0;
-        int N, P, batch, R, tail;
+        int N, P, batch, R, wpi;
         LmInit init;
     } graph_key{};
     bool defer_sync = false;      // one-shot path: stage syncs and checks are batched at the end
     double dbg_enqueue_s = 0, dbg_total_s = 0;
     int dbg_runs = 0;
     bool graph_dirty = true, use_graph = true, adaptive_batch = true, spin_wait = true;
-    bool tail_advance = false;    // experiment (-DCCAL_EXP_TAIL builds + CCAL_TAIL=1): the LM state machine advances at the tail of the
-                                  // sweep launch instead of the next launch's prologue (measured slower: profiles/r04_tail_advance_probe.txt)
+    int wpi = 1;                  // waves per image of the sweep, resolved once per problem (lm_waves_per_image)
+    bool use_solo = true;         // fits of a few images on one GPU run all their trials in ONE launch (CCAL_NO_SOLO=1: launch per trial)
+    bool run_solo = false;
     // a solve in flight (lm_begin .. lm_end)
     double run_t0 = 0;
     long run_max_trials = 0, run_trials = 0;
@@ -190,9 +189,9 @@ int ccal_create(int device, ccal_ctx **out) {
     HIPCHK(hipMalloc(&c->d_st, sizeof(LmState) * 2));          // S_k lives in d_st[k & 1]
     HIPCHK(hipMalloc(&c->d_st_scratch, sizeof(LmState) * 2));
     HIPCHK(hipMalloc(&c->d_red, sizeof(double) * NRED));
-    HIPCHK(hipMalloc(&c->d_acc, ACC_BYTES + TAIL_BYTES));
-    HIPCHK(hipMalloc(&c->d_acc_scratch, ACC_BYTES + TAIL_BYTES));
-    HIPCHK(hipMemset(c->d_acc_scratch, 0, ACC_BYTES + TAIL_BYTES));
+    HIPCHK(hipMalloc(&c->d_acc, ACC_BYTES));
+    HIPCHK(hipMalloc(&c->d_acc_scratch, ACC_BYTES));
+    HIPCHK(hipMemset(c->d_acc_scratch, 0, ACC_BYTES));
     HIPCHK(hipMalloc(&c->d_foc_red, sizeof(double) * NFOC));
     HIPCHK(hipMalloc(&c->d_foc_acc, sizeof(long long) * 2 * LM_FOC_ACC_WORDS));
     HIPCHK(hipMalloc(&c->d_fail, sizeof(int) * 4));
@@ -208,11 +207,9 @@ int ccal_create(int device, ccal_ctx **out) {
     if (b && atoi(b) > 0) { c->lm_batch = atoi(b); c->adaptive_batch = false; }
     const char *g = getenv("CCAL_NO_GRAPH");
     if (g && atoi(g) != 0) c->use_graph = false;
+    if (const char *so = getenv("CCAL_NO_SOLO")) c->use_solo = atoi(so) == 0;
     const char *sp = getenv("CCAL_NO_SPIN");
     if (sp && atoi(sp) != 0) c->spin_wait = false;
-#ifdef CCAL_EXP_TAIL
-    if (const char *tl = getenv("CCAL_TAIL")) c->tail_advance = atoi(tl) != 0;
-#endif
     if (const char *hm = getenv("CCAL_INIT_HMODE")) {       // experiments: 0 = OpenCV's own sequence (DLT + polish), 1, 2
         const int v = atoi(hm);
         if (v >= 0 && v <= 2) c->init_hmode = v;
@@ -456,6 +453,7 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
     if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));   // `obj` may be released by the caller after return
     c->P = P; c->N = N; c->width = width; c->height = height; c->aspect = aspect; c->flags = flags;
     c->max_iter = max_iter; c->eps = eps;
+    c->wpi = lm_waves_per_image(N, P, false);
     const int sweep_grid = std::min(lm_sweep_blocks(N), lm_max_grid());
     const int old_R = c->acc_R;
     c->acc_R = lm_acc_replicas(sweep_grid);
@@ -779,38 +777,23 @@ static int wait_progress(ccal_ctx *c, long target_trials) {
     return CCAL_OK;
 }
 
-static unsigned int *tail_counters(ccal_ctx *c) {
-    return reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(c->d_acc) + ACC_BYTES);
-}
-
 static TrialLaunch base_launch(ccal_ctx *c) {
     TrialLaunch t;
     t.obj = c->d_obj; t.img = c->d_img; t.blk = c->d_blk; t.st = c->d_st; t.acc = c->d_acc; t.R = c->acc_R;
     t.trace = c->d_trace; t.host_result = c->h_st; t.host_progress = progress_word(c);
     t.intr0 = c->d_intr0; t.ext0 = c->d_ext0; t.ext0_stride = EXT; t.init = make_init(c);
-    t.N = c->N; t.P = c->P;
+    t.N = c->N; t.P = c->P; t.wpi = c->wpi;
     // the first launch of every solve reports the initialisation's flags and start intrinsics to the host (finish_init_check)
     t.init_fail = c->d_fail; t.host_init_intr = reinterpret_cast<double *>(c->h_flags + 4); t.host_init_fail = c->h_flags;
     return t;
 }
 
-// the exchange is fused into the trial launch unless the ranks of this fit run many workgroups each (prologue form: every
-// workgroup polls; the tail-advance flow exchanges from ONE workgroup, whatever the grid)
+// the exchange is fused into the trial launch unless the ranks of this fit run many workgroups each (every workgroup polls)
 static bool xchg_fused(const ccal_ctx *c) {
     if (c->p2p_no_fuse) return false;  // other processes' ranks share this GPU: a waiting rank must hold one CU, not a grid
-    if (c->tail_advance) return true;
     const int64_t ng = c->n_global > 0 ? c->n_global : c->N;
     const int64_t per_rank = (ng + c->world - 1) / (c->world > 0 ? c->world : 1);
     return lm_sweep_blocks((int)per_rank) <= FUSED_XCHG_MAX_BLOCKS;
-}
-
-// Does this context's solve advance the state machine at the tail of the sweep launches?  Only where the sums of a trial
-// are complete inside the launch: one GPU, or the fused xGMI exchange; a row summed BETWEEN two launches (RCCL, the host
-// hook, k_lm_exchange, the split send / receive of shards sharing a stream) is consumed by the next launch's prologue.
-static bool uses_tail(const ccal_ctx *c) {
-    if (!c->tail_advance) return false;
-    if (via_p2p(c)) return !c->p2p_split && xchg_fused(c);
-    return !sharded(c);
 }
 
 // Launch trial k (k_lm_trial): its prologue consumes the exact accumulators of trial k - 1 -- directly
@@ -822,12 +805,7 @@ static int enqueue_trial(ccal_ctx *c, hipStream_t stream, int k, bool final_only
     t.first = k == 0;
     t.final_only = final_only ? 1 : 0;
     if (via_p2p(c)) t.p2p = &c->p2p->dev();
-    if (uses_tail(c)) {
-        if (final_only) return CCAL_OK;       // the tail of the last sweep has already advanced and reported
-        t.tail = 1;
-        t.tail_cnt = tail_counters(c);
-        if (via_p2p(c)) t.xchg_fused = 1;
-    } else if (k > 0) {
+    if (k > 0) {
         if (via_p2p(c)) {
             if (c->p2p_split) {
                 // this shard's row was sent by enqueue_send(k), like every other shard's of this stream: collect them
@@ -908,7 +886,7 @@ static int lm_prepare(ccal_ctx *c) {
     if (c->acc_dirty) {
         // first solve of a problem, or the last one did not end with its terminating launch (which leaves
         // the accumulators cleared): start from zeros
-        HIPCHK(hipMemsetAsync(c->d_acc, 0, ACC_BYTES + TAIL_BYTES, c->stream));
+        HIPCHK(hipMemsetAsync(c->d_acc, 0, ACC_BYTES, c->stream));
     }
     c->acc_dirty = true;               // until this solve is seen to have ended with its terminating launch
     c->run_graphed = false;
@@ -920,13 +898,26 @@ static int lm_begin(ccal_ctx *c) {
     if (rc0) return rc0;
     if (via_p2p(c) && c->p2p_split)
         return fail(CCAL_E_STATE, "ccal_lm_run: this context shares its stream with other shards (ccal_calibrate_multi drives it)");
+    // A few images on one GPU: every trial in ONE launch of one workgroup (k_lm_trial<.., SOLO>): the trial-to-trial hand-off is a
+    // workgroup barrier instead of a kernel boundary + accumulator round trip; same bits as the launch-per-trial form
+    c->run_solo = c->use_solo && !sharded(c) && !c->time_sweeps && c->N <= lm_solo_max_images();
+    if (c->run_solo) {
+        const double t_enq0 = now_s();
+        TrialLaunch t = base_launch(c);
+        t.k = 0; t.first = 1; t.solo = 1;
+        t.max_trials = (int)c->run_max_trials;
+        HIPCHK(launch_lm_trial(c->stream, t));
+        c->run_trials = c->run_max_trials;          // (the launch reports once: done, or budget exhausted)
+        c->dbg_enqueue_s += now_s() - t_enq0;
+        return CCAL_OK;
+    }
     c->run_graphed = c->use_graph && !c->time_sweeps && (!sharded(c) || via_p2p(c));
     if (c->run_graphed) {
         ccal_ctx::GraphKey key;
         memset(&key, 0, sizeof key);
         key.obj = c->d_obj; key.img = c->d_img; key.blk = c->d_blk; key.st = c->d_st; key.acc = c->d_acc; key.R = c->acc_R;
         key.red = c->d_red; key.trace = c->d_trace; key.intr0 = c->d_intr0; key.ext0 = c->d_ext0;
-        key.N = c->N; key.P = c->P; key.batch = c->lm_batch; key.init = make_init(c); key.tail = uses_tail(c) ? 1 : 0;
+        key.N = c->N; key.P = c->P; key.wpi = c->wpi; key.batch = c->lm_batch; key.init = make_init(c);
         if (c->graph_dirty || !c->g_first || memcmp(&key, &c->graph_key, sizeof key) != 0) {
             const int rc = capture_graph(c, &c->g_first);
             if (rc) return rc;
@@ -984,6 +975,7 @@ static int lm_end(ccal_ctx *c) {
     c->stats.rejected = r.rejected; c->stats.lambda_lg10 = r.lambda_lg10; c->stats.n_bad = r.n_bad;
     c->stats.final_err = r.prev_err; c->stats.rel_step = r.rel_step;
     c->stats.rms = std::sqrt(r.prev_err / ((double)r.N_global * (double)c->P));
+    c->stats.sweep_form = lm_sweep_form(c->N, c->wpi, via_p2p(c), c->run_solo);
     c->stats.sweep_us = 0.0;
     c->stats.timed_sweeps = 0;
     c->stats.solve_kernels_us = 0.0;
@@ -1012,13 +1004,9 @@ static int lm_end(ccal_ctx *c) {
     c->have_result = true;
     // size the next graph to the trials this problem needed (a surplus launch costs a kernel
     // boundary); a different problem simply continues trial by trial above
-    if (c->adaptive_batch && r.trials != c->lm_batch) {
+    if (c->adaptive_batch && !c->run_solo && r.trials != c->lm_batch) {
         c->lm_batch = r.trials < 1 ? 1 : (r.trials > 48 ? 48 : r.trials);
         c->graph_dirty = true;
-    }
-    if (r.status == -6) {
-        c->acc_dirty = true;           // accumulators / counters are in an unknown state: zero them before the next solve
-        return fail(CCAL_E_DEVICE, "ccal_lm_run: a sweep workgroup never reported its sums (tail-advance wait expired)");
     }
     if (r.status == -4) return fail(CCAL_E_NONFINITE, "ccal_lm_run: non-finite reprojection error on the device");
     if (r.status == -3) return fail(CCAL_E_DEGENERATE, "ccal_lm_run: reduced intrinsic system not positive definite");
@@ -1672,10 +1660,6 @@ int ccal_time_sweep(ccal_ctx *c, int32_t reps, double *avg_us) {
     t.st = c->d_st_scratch; t.trace = nullptr; t.host_result = nullptr; t.host_progress = nullptr;
     t.acc = c->d_acc_scratch;
     t.first = 1; t.k = 0;
-    if (c->tail_advance) {             // the flow a single-GPU solve runs: the mean then includes workgroup 0's tail
-        t.tail = 1;
-        t.tail_cnt = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(c->d_acc_scratch) + ACC_BYTES);
-    }
     if (c->have_result) {
         const LmState *fin = c->d_st + (c->h_st->trials & 1);
         t.intr0 = reinterpret_cast<const double *>(reinterpret_cast<const char *>(fin) + offsetof(LmState, intr_prev));

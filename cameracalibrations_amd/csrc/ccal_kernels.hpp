@@ -11,6 +11,8 @@ namespace ccal {
 // ccal_lm.hip
 int lm_sweep_blocks(int N);
 int lm_waves_per_image(int N, int P, bool fused);   // 1, 2 or 4: multi-pass boards are split over the waves of a workgroup while that fits the chip
+int lm_solo_max_images();        // fits of at most this many images on one GPU run all their trials in ONE launch (TrialLaunch::solo)
+int lm_sweep_form(int N, int wpi, bool xchg, bool solo);   // ccal_stats.sweep_form of such a sweep
 int lm_max_grid();               // workgroups of k_lm_trial resident on the current device (the sweep grid is capped there)
 struct TrialLaunch {              // one launch of k_lm_trial (see ccal_lm.hip)
     const float *obj = nullptr, *img = nullptr;
@@ -29,16 +31,15 @@ struct TrialLaunch {              // one launch of k_lm_trial (see ccal_lm.hip)
     int N = 0, P = 0, k = 0, first = 0, final_only = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;   // optional: timestamps of this dispatch
     const P2PDev *p2p = nullptr;  // image-sharded fit: launch the exchanging instantiation
-    int xchg_fused = 0;           // ... whose prologue (or, tail flow, workgroup 0's tail) runs the row exchange itself
-    int tail = 0;                 // tail-advance flow: workgroup 0 advances the state machine at the END of this launch (no
-                                  // row_in, no terminating launch); every launch of a solve must then use it
-    unsigned int *tail_cnt = nullptr;   // [LM_TAIL_COUNTERS] zeroed words in device memory (zero again after every launch)
+    int xchg_fused = 0;           // ... whose prologue runs the row exchange itself
+    int wpi = 0;                  // waves per image as ccal_set_problem resolved it (lm_waves_per_image); 0: resolve at the launch
+    int solo = 0;                 // one launch, one workgroup, every trial of the solve (N <= lm_solo_max_images(), single GPU; k = 0):
+    int max_trials = 0;           // ... up to this many trials
     int *init_fail = nullptr;           // first launch: the init stages' four failure words (device; word 2 = "a pose stage has run since
                                         // the last report", cleared here) and the start intrinsics are
     double *host_init_intr = nullptr;   // copied to pinned host memory by workgroup 0 (all three set, or none)
     int *host_init_fail = nullptr;
 };
-constexpr int LM_TAIL_COUNTERS = 64;
 hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t);
 int lm_acc_replicas(int nblocks);
 // diagnostics: n_rows rows of 68 doubles added like n_rows workgroups would, read back like a prologue does -> out[68]

@@ -31,8 +31,8 @@
 //                Instantiations k_lm_trial<FLOW, LOOP, KIND, WPI>: looping grid or one image group per workgroup; first / later /
 //                terminating launch; WPI = 2 or 4 waves per image for boards of more than 64 corners while the split grid is at
 //                most one workgroup per compute unit (each wave takes an even share of the corners, the partial Grams meet in
-//                LDS); FLOW = the prologue forms described here (shipped) or the tail-advance experiment of round 4
-//                (-DCCAL_EXP_TAIL builds only: profiles/r04_tail_advance_probe.txt).
+//                LDS); FLOW = the prologue alone, or with the xGMI row exchange fused in (the tail-advance flows of round 4,
+//                measured slower, are kept as tools/experiments/r04_tail_advance.patch: profiles/r04_tail_advance_probe.txt).
 // A solve of T trials is T + 1 launches of k_lm_trial (the last one runs the prologue only and
 // leaves the accumulators cleared for the next solve).
 // A rejected step costs one extra sweep of the accepted point with the larger lambda.
@@ -382,7 +382,6 @@ __device__ __forceinline__ void acc_read_issue(const long long *__restrict__ acc
 // Replica sums -> LDS.  Every replica's word is split on its own into the two exactly representable halves acc_decode()
 // takes and the halves are added as doubles: one address receives at most ACC_MAX_ADDS adds of 52-bit payloads (no int64
 // overflow per replica), while the total over all replicas of a grid of more than 2^11 workgroups would not fit an int64.
-template <bool SC1 = false>
 __device__ __forceinline__ void acc_read_stage(const long long *__restrict__ acc, int R, AccPart *s_acc, int tid, const AccRegs &q) {
     if (tid >= ACC_PAIRS) return;
     AccPart p0, p1;
@@ -394,12 +393,7 @@ __device__ __forceinline__ void acc_read_stage(const long long *__restrict__ acc
         longlong2 v[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            if (r0 + r >= R) v[r] = make_longlong2(0, 0);
-            else if (SC1) {
-                const long long *w = acc + (size_t)(r0 + r) * ACC_ROW + 2 * tid;
-                v[r].x = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v[r].y = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else v[r] = src[(size_t)(r0 + r) * ACC_PAIRS];
+            v[r] = (r0 + r >= R) ? make_longlong2(0, 0) : src[(size_t)(r0 + r) * ACC_PAIRS];
         }
 #pragma unroll
         for (int r = 0; r < 8; r++) { acc_part_add(p0, v[r].x); acc_part_add(p1, v[r].y); }
@@ -427,68 +421,52 @@ __device__ __forceinline__ double acc_row_decode(const AccPart *s_acc, int col) 
     return v;
 }
 
-// this workgroup's 68 sums -> limbs -> integer atomics into one replica (threads 0..67).
-// Returns a value that depends on what the atomics FETCHED: a caller that consumes it (acc_wait) has thereby waited until
-// its adds were performed at the memory side -- what the tail-advance flow needs before it reports the workgroup done.
-__device__ __forceinline__ long long acc_add(long long *__restrict__ dst, int col, double v) {
+// this workgroup's 68 sums -> limbs -> integer atomics into one replica (threads 0..67)
+__device__ __forceinline__ void acc_add(long long *__restrict__ dst, int col, double v) {
     int j, flag;
     int64_t lo, hi;
-    long long seen = 0;
     acc_split(v, j, lo, hi, flag);
 #ifdef CCAL_EXP_NO_ACC             // timing experiment only (no sums at all)
-    if (col >= 0) return 0;
+    if (col >= 0) return;
 #endif
 #ifdef CCAL_EXP_STORE_NOT_ATOMIC   // timing experiment only (wrong sums): what the atomics cost against plain stores
     dst[j * NRED + col] = lo;
     dst[(j + 1) * NRED + col] = hi;
-    return 0;
+    return;
 #endif
     if (flag) {
-        seen ^= __hip_atomic_fetch_add(dst + (flag - 1) * NRED + ACC_FLAG_COL, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(dst + (flag - 1) * NRED + ACC_FLAG_COL, 1ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-        if (lo != 0) seen ^= __hip_atomic_fetch_add(dst + j * NRED + col, (long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (hi != 0) seen ^= __hip_atomic_fetch_add(dst + (j + 1) * NRED + col, (long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return seen;
-}
-
-// consume what acc_add fetched: the compiler has to keep the atomics in their returning form and wait for them here
-__device__ __forceinline__ void acc_wait(long long seen) {
-    asm volatile("" ::"v"((int)seen), "v"((int)(seen >> 32)) : "memory");
-}
-
-// ---- tail-advance flow: "all workgroups of this launch have added their sums" ---------------------------------------
-// Every workgroup, once its own adds have been performed (acc_wait + barrier), adds 1 to one of TAIL_CNT counters
-// (workgroup index mod TAIL_CNT: a few adds per address, no pile-up on one word); workgroup 0 -- the one that advances the
-// state machine at the tail of the launch -- polls their sum.  It only ever waits at the very end of its own work, for
-// workgroups of the same launch that are resident or will be as soon as a slot frees; the wait is bounded all the same.
-constexpr int TAIL_CNT = LM_TAIL_COUNTERS;
-constexpr long long TAIL_BUDGET_TICKS = 300000000ll;   // 3 s on the 100 MHz wall clock
-
-__device__ __forceinline__ bool tail_wait_all(unsigned int *cnt, int lane, unsigned int want) {
-    const long long t0 = wall_clock64();
-    for (;;) {
-        const unsigned int mine = __hip_atomic_load(cnt + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double tot = wave_sum((double)mine);       // (small integers: exact)
-        if (tot >= (double)want) return true;
-        if (wall_clock64() - t0 > TAIL_BUDGET_TICKS) return false;
-        __builtin_amdgcn_s_sleep(1);
+        if (lo != 0) __hip_atomic_fetch_add(dst + j * NRED + col, (long long)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hi != 0) __hip_atomic_fetch_add(dst + (j + 1) * NRED + col, (long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// the accumulators of a finished launch, read past the caches (they were formed by memory-side atomics of all XCDs): thread
-// t < ACC_PAIRS takes pair t of every replica
-__device__ __forceinline__ void acc_read_issue_sc1(const long long *__restrict__ acc, int R, int tid, AccRegs &q) {
-    const long long *src = acc + 2 * (tid < ACC_PAIRS ? tid : 0);
+// What the accumulators make of `n` workgroups' sums of one column, without the memory: every partial is split into its limbs,
+// the limbs are added exactly and the total is decoded like a prologue decodes it (acc_read_stage + acc_decode) -- the one-launch
+// solve of a few images (k_lm_trial<.., SOLO>) reproduces the bits of the launch-per-trial form with it.  flags: bit 0 = a NaN
+// contribution, bit 1 = an out-of-range one.
+template <int NP>
+__device__ __forceinline__ double acc_sum_local(const double (&p)[NP], int &flags) {
+    AccPart part[ACC_LIMBS];
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        if (tid < ACC_PAIRS && r < R) {
-            q.v[r].x = __hip_atomic_load(src + (size_t)r * ACC_ROW, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            q.v[r].y = __hip_atomic_load(src + (size_t)r * ACC_ROW + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            q.v[r] = make_longlong2(0, 0);
+    for (int j = 0; j < ACC_LIMBS; j++) part[j].hi = part[j].lo = 0.0;
+    flags = 0;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        int j, flag;
+        int64_t lo, hi;
+        acc_split(p[i], j, lo, hi, flag);
+        flags |= flag;
+#pragma unroll
+        for (int jj = 0; jj < ACC_LIMBS; jj++) {
+            if (flag == 0 && jj == j) acc_part_add(part[jj], lo);
+            if (flag == 0 && jj == j + 1) acc_part_add(part[jj], hi);
         }
     }
+#pragma unroll
+    for (int j = 0; j < ACC_LIMBS; j++) acc_part_norm(part[j]);
+    return acc_decode(part);
 }
 
 // clear `n_bufs` consecutive accumulator buffers (one workgroup, plain 16-byte stores)
@@ -517,12 +495,12 @@ struct TrialArgs {
     int first;                    // k == 0: build S_0 instead of advancing
     int final_only;               // prologue only (detect termination, report to the host)
     int xchg_fused;               // image-sharded fit: the prologue exchanges the local row with the peer GPUs
+    int max_trials;               // SOLO launches: the solve's trial budget (the launch ends there even if the solve has not)
     TraceRec *trace;
     LmState *host_result;
     unsigned long long *host_progress;
     double *gram_out;
     LmInit init;
-    unsigned int *tail_cnt;       // [TAIL_CNT] "workgroup done" counters of the tail-advance flows (zero between launches)
     int *init_fail;               // first launch of a solve, workgroup 0: the initialisation's failure words (device) ...
     double *host_init_intr;       // ... and the start intrinsics go to pinned host memory (a pipelined fit needs no read-back kernel)
     int *host_init_fail;
@@ -587,31 +565,37 @@ __device__ void lm_boot(LmState *ls, const LmInit &init, const double *intr0, in
 // FLOW: where the LM state machine is advanced.
 //   FLOW_PRO / FLOW_PRO_XCHG  in the PROLOGUE of the next launch, by every workgroup redundantly (from the accumulators,
 //                  from an all-reduced row, or -- XCHG -- after the fused row exchange); a solve of T trials is T + 1 launches.
-//   FLOW_TAIL / FLOW_TAIL_XCHG  at the TAIL of the launch that produced the sums, ONCE: every workgroup reports when its adds
-//                  have been performed, workgroup 0 waits for all reports at the end of its own sweep, reads the totals,
-//                  (XCHG: exchanges the row with the peer GPUs -- one workgroup polls, not a grid,) runs lm_advance_wave
-//                  and stores S_{k+1}; the next launch's prologue is one 0.9 KB load of that state instead of 22 KB of
-//                  accumulators + decode + a 3.9 k-cycle advance in every workgroup, and the solve needs no terminating
-//                  launch: the tail that sees `done` reports to the host itself.  Nothing else waits inside a launch.
-enum : int { FLOW_PRO = 0, FLOW_PRO_XCHG = 1, FLOW_TAIL = 2, FLOW_TAIL_XCHG = 3 };
-template <int FLOW, bool LOOP, int KIND, int WPI = 1>
-__global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(const TrialArgs A) {
+enum : int { FLOW_PRO = 0, FLOW_PRO_XCHG = 1 };
+// SOLO: a fit of at most SOLO_WAVES images on one GPU runs EVERY trial in this one launch, one workgroup of SOLO_WAVES waves: the
+//   sums of a trial stay in LDS (added up exactly like the accumulators would add the sums of the four-image workgroups of the
+//   launch-per-trial form: same bits), wave 0 advances the state machine between two sweeps, a barrier is the hand-off -- no
+//   kernel boundary, accumulator round trip, cold-cache prologue or terminating launch per trial, no graph.  KIND is 1.
+//   Four waves, one per SIMD: measured (profiles/r05_one_launch_solve_probe.txt) a 5-sweep solve of 4 images takes 42.6 us
+//   instead of 50.0; with eight waves (CCAL_SOLO_WAVES=8: up to 8 images) two sweeping waves share a SIMD, a trial grows by
+//   1.6 us and the form returns nothing (6 images: 50.6 against 49.4 us), so beyond four images a trial stays a launch.
+#ifndef CCAL_SOLO_WAVES
+#define CCAL_SOLO_WAVES 4
+#endif
+constexpr int SOLO_WAVES = CCAL_SOLO_WAVES;
+template <int FLOW, bool LOOP, int KIND, int WPI = 1, bool SOLO = false>
+#ifndef CCAL_SOLO_MINW
+#define CCAL_SOLO_MINW 1
+#endif
+__global__ __launch_bounds__((SOLO ? SOLO_WAVES : WAVES) * 64, SOLO ? CCAL_SOLO_MINW : CCAL_TRIAL_MIN_WAVES) void k_lm_trial(const TrialArgs A) {
     constexpr bool XCHG = FLOW == FLOW_PRO_XCHG;
-    constexpr bool TAIL = FLOW >= FLOW_TAIL;
+    static_assert(!SOLO || (FLOW == FLOW_PRO && !LOOP && KIND == 1 && WPI == 1), "one-launch solves: single GPU, one image per wave");
+    constexpr int NW = SOLO ? SOLO_WAVES : WAVES;   // waves of the workgroup
     static_assert(WPI == 1 || WPI == 2 || WPI == 4, "waves per image");
     static_assert(WPI == 1 || (!LOOP && KIND != 2), "split images: one group per workgroup");
-    static_assert(!(TAIL && KIND == 2), "the tail-advance flows have no terminating launch");
-    constexpr int IPW = WAVES / WPI;             // images per workgroup
-    __shared__ __attribute__((aligned(16))) double s_wave[WAVES * TILE_D];
-    __shared__ __attribute__((aligned(16))) double s_red[WAVES * NRED];
+    constexpr int IPW = NW / WPI;                // images per workgroup
+    __shared__ __attribute__((aligned(16))) double s_wave[NW * TILE_D];
+    __shared__ __attribute__((aligned(16))) double s_red[NW * NRED];
     __shared__ __attribute__((aligned(16))) double s_rs[NRED];
     __shared__ __attribute__((aligned(16))) double s_S[9 * SROW];
     __shared__ LmState ls;
-    __shared__ unsigned int s_seq;
-    __shared__ int s_tail_ok;
     double *s_all = s_wave;       // XCHG: the peers' rows are staged in the (not yet used) tile space
     AccPart *s_acc = reinterpret_cast<AccPart *>(s_wave + P2P_MAX_RANKS * NRED);   // staged accumulator sums, likewise
-    static_assert(P2P_MAX_RANKS * NRED + 2 * ACC_ROW <= WAVES * TILE_D, "prologue staging exceeds the tile space");
+    static_assert(P2P_MAX_RANKS * NRED + 2 * ACC_ROW <= NW * TILE_D, "prologue staging exceeds the tile space");
 
     const int tid = threadIdx.x;
     STAMP(0);
@@ -626,7 +610,6 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         g_wg_times[blockIdx.x * 4 + 3] = ((unsigned long long)xcc << 32) | hw;
     }
 #endif
-    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = A.N, P = A.P;
 #ifdef CCAL_STAMPS
@@ -665,19 +648,28 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     const int cend = WPI == 1 ? P : min(cbeg + cpw, P);
     const size_t acc_buf = (size_t)A.R * ACC_ROW;   // int64 words per accumulator buffer
 
+    // kk = the trial this pass of the kernel runs: the launch's one trial -- or, SOLO, every trial of the solve in turn
+    const int tid_launch = tid;
+    // One trial.  `first` (build S_0 instead of advancing) is a compile-time constant of each copy: the launch's kind -- or, SOLO,
+    // the peeled first trial and the loop over the later ones.  Returns false when the launch is over.
+    auto trial = [&](auto first_c, const int kk) __attribute__((always_inline)) -> bool {
+    constexpr bool first = decltype(first_c)::value;
+    // SOLO: the thread index is made opaque once per trial, so that nothing derived from it (lane masks, per-lane addresses, the
+    // packed-index decode) is hoisted out of the trial loop and kept alive across the sweep: that hoisting cost the one-launch form
+    // 34 spilled vector registers at its two waves per SIMD
+    int tid_trial = tid_launch;
+    if constexpr (SOLO) asm volatile("" : "+v"(tid_trial));
+    const int tid = tid_trial, lane = tid & 63;
     // ---- 0. loads that do not depend on the LM state are issued up front: the previous state, the
     //         accumulators of the previous trial, both parities of the block head (rvec,tvec | U | pd)
     //         -- or the start pose -- and the first 64 corners ----
-    // (tail-advance flows: S_k was stored into st[k & 1] by the tail of launch k - 1; otherwise S_{k-1} sits in st[(k - 1) & 1])
-    const LmState *prev = A.st + ((TAIL ? A.k : A.k - 1) & 1);
+    const LmState *prev = A.st + ((kk - 1) & 1);         // S_{k-1}
     double sw = 0.0, row_v = 0.0;
     AccRegs q;
-    if ((KIND != 0)) {
+    if (!first && !SOLO) {
         if (tid < STATE_WORDS) sw = reinterpret_cast<const double *>(prev)[tid];
-        if constexpr (!TAIL) {
-            if (A.row_in != nullptr) { if (tid < NRED) row_v = A.row_in[tid]; }
-            else acc_read_issue(A.acc + (size_t)((A.k + 2) % 3) * acc_buf, A.R, tid, q);
-        }
+        if (A.row_in != nullptr) { if (tid < NRED) row_v = A.row_in[tid]; }
+        else acc_read_issue(A.acc + (size_t)((kk + 2) % 3) * acc_buf, A.R, tid, q);
     }
     // block words lane (ha) and 64 + lane (hb) of this image.  Trial k - 1 wrote buffer (k - 1) & 1; unless its point
     // was a rejected candidate (rare) that is the accepted point's block, so it is requested before the state is known
@@ -687,18 +679,17 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     float2 uv = make_float2(0.f, 0.f);
     float m0 = 0.f, m1 = 0.f, m2 = 0.f;
     if ((KIND != 2)) {
-        if ((KIND == 0)) {
+        if (first) {
             hb = (lane >= BLK_EXT - 64 && lane < BLK_EXT - 64 + 6) ? A.ext0[(size_t)ii * A.ext0_stride + lane - (BLK_EXT - 64)] : 0.0;
         } else {
-            const double *bp = A.blk + ((size_t)((A.k - 1) & 1) * N + ii) * BLK;
+            const double *bp = A.blk + ((size_t)((kk - 1) & 1) * N + ii) * BLK;
             ha = bp[lane];
             hb = bp[64 + lane];
         }
         uv = img2[pc0];                         // coalesced 8 B per lane
         m0 = A.obj[3 * pc0]; m1 = A.obj[3 * pc0 + 1]; m2 = A.obj[3 * pc0 + 2];
-        // the buffer the NEXT trial adds into was last read one launch ago: clear it now (tail flows: the tail that reads a
-        // buffer clears it, every buffer is zero between launches)
-        if (!TAIL && blockIdx.x == 0) acc_clear(A.acc + (size_t)((A.k + 1) % 3) * acc_buf, A.R, 1, tid);
+        // the buffer the NEXT trial adds into was last read one launch ago: clear it now (SOLO: no accumulators in use)
+        if (!SOLO && blockIdx.x == 0) acc_clear(A.acc + (size_t)((kk + 1) % 3) * acc_buf, A.R, 1, tid);
     }
     int oa, ob;                                 // (a, b) of the packed S0 entry this lane assembles
     tri_decode(lane < 45 ? lane : 0, oa, ob);
@@ -718,18 +709,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     // ---- 1. the state of this trial, S_k, in LDS (every workgroup computes the same bits) ----
     unsigned int seq = 0;
     if constexpr (XCHG) seq = __hip_atomic_load(A.p2p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if constexpr (FLOW == FLOW_TAIL_XCHG) {
-        // only workgroup 0 exchanges (at its tail); one thread reads -- and, first launch of a solve, advances -- the sequence number
-        if (blockIdx.x == 0 && tid == 0) {
-            unsigned int e = __hip_atomic_load(A.p2p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (KIND == 0) {
-                e += 1u;
-                __hip_atomic_store(A.p2p.epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            s_seq = e;                          // (read after the barriers of the sweep)
-        }
-    }
-    if ((KIND == 0)) {
+    if (first) {
         if (blockIdx.x == 0 && A.host_init_intr != nullptr && tid < NINTR + 4) {
             // what the initialisation stages left for the host: nine start intrinsics, four failure words (ccal_fit reads them
             // after the solve; they used to travel by a kernel of their own between the pose stage and this launch).  Only when
@@ -748,26 +728,17 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         if constexpr (XCHG)
             if (blockIdx.x == 0 && tid == 0)
                 __hip_atomic_store(A.p2p.epoch, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if constexpr (TAIL) {
-        if (tid < STATE_WORDS) reinterpret_cast<double *>(&ls)[tid] = sw;
+    } else if constexpr (SOLO) {
+        // the sums of trial k - 1 are in s_rs / s_S (end of the previous pass), the state has stayed in LDS
+        if (wave == 0) lm_advance_wave<true, false>(&ls, s_rs, s_S, A.trace, lane, kk);
         __syncthreads();
-        STAMP(11);
-        STAMP(12);
-        if (ls.done) {
-            // solve already terminated: surplus launch; the terminal state is carried along for the launches after it
-            if (blockIdx.x == 0) {
-                LmState *nxt = A.st + ((A.k + 1) & 1);
-                if (tid < STATE_WORDS) reinterpret_cast<double *>(nxt)[tid] = reinterpret_cast<const double *>(&ls)[tid];
-            }
-            return;
-        }
     } else {
         if (tid < STATE_WORDS) reinterpret_cast<double *>(&ls)[tid] = sw;
         if (A.row_in != nullptr) {
             if (tid < NRED) s_rs[tid] = row_v;
             if (tid < RED_DA) { s_S[oa * SROW + ob] = row_v; s_S[ob * SROW + oa] = row_v; }
         } else {
-            acc_read_stage(A.acc + (size_t)((A.k + 2) % 3) * acc_buf, A.R, s_acc, tid, q);
+            acc_read_stage(A.acc + (size_t)((kk + 2) % 3) * acc_buf, A.R, s_acc, tid, q);
         }
         __syncthreads();
         STAMP(11);
@@ -776,11 +747,11 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
             // later launch of the batch sees it too (none of them sweeps or exchanges again); the
             // terminating launch leaves all accumulators cleared for the next solve.
             if (blockIdx.x == 0) {
-                LmState *cur = A.st + (A.k & 1);
+                LmState *cur = A.st + (kk & 1);
                 if (tid < STATE_WORDS) reinterpret_cast<double *>(cur)[tid] = reinterpret_cast<const double *>(&ls)[tid];
                 if ((KIND == 2)) acc_clear(A.acc, A.R, ACC_BUFS, tid);
             }
-            return;
+            return false;
         }
         if (A.row_in == nullptr) {
             if (tid < NRED) {
@@ -792,7 +763,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         }
         if constexpr (XCHG)
             if (A.xchg_fused) {
-                p2p_exchange_rows(A.p2p, p2p_tag(seq, (unsigned)A.k), p2p_slot(seq, (unsigned)A.k), s_rs, s_all, NRED, tid,
+                p2p_exchange_rows(A.p2p, p2p_tag(seq, (unsigned)kk), p2p_slot(seq, (unsigned)kk), s_rs, s_all, NRED, tid,
                                   blockIdx.x == 0);
                 if (tid < RED_DA) {               // the symmetric copy again, now of the sum over the ranks (wave 0 only)
                     const double v = s_rs[tid];
@@ -803,16 +774,17 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
             }
         STAMP(12);
         if (wave == 0) {
-            if ((KIND == 2)) lm_advance_wave<true, true>(&ls, s_rs, s_S, A.trace, lane, A.k);     // (one workgroup: it keeps the books)
-            else if (blockIdx.x == 0) lm_advance_wave<true, false>(&ls, s_rs, s_S, A.trace, lane, A.k);
-            else lm_advance_wave<false, false>(&ls, s_rs, s_S, nullptr, lane, A.k);
+            if ((KIND == 2)) lm_advance_wave<true, true>(&ls, s_rs, s_S, A.trace, lane, kk);     // (one workgroup: it keeps the books)
+            else if (blockIdx.x == 0) lm_advance_wave<true, false>(&ls, s_rs, s_S, A.trace, lane, kk);
+            else lm_advance_wave<false, false>(&ls, s_rs, s_S, nullptr, lane, kk);
         }
         __syncthreads();
     }
     STAMP(1);
     WG_TIME(1);
-    if (!TAIL && blockIdx.x == 0) {
-        LmState *cur = A.st + (A.k & 1);
+    const bool budget_out = SOLO && kk >= A.max_trials;   // the launch ends here even if the solve has not (the host reports it)
+    if (blockIdx.x == 0 && (!SOLO || ls.done || budget_out)) {
+        LmState *cur = A.st + (kk & 1);
         if (tid < STATE_WORDS) reinterpret_cast<double *>(cur)[tid] = reinterpret_cast<const double *>(&ls)[tid];
         if (A.host_progress != nullptr && tid < 64) {
             // wave 0 alone talks to the host: the state header when the solve terminates, then the
@@ -830,12 +802,12 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
         // consumed before the barrier above); an unfinished one keeps its input for the trial that follows
         if ((KIND == 2) && ls.done) acc_clear(A.acc, A.R, ACC_BUFS, tid);
     }
-    if (ls.done || (KIND == 2)) return;
+    if (ls.done || (KIND == 2) || budget_out) return false;
 
     const int mode = ls.mode;
     const int par = ls.parity;                  // buffer holding the accepted point's blocks
-    const int cand = A.k & 1;                   // buffer this sweep writes (never the one an evaluating sweep reads)
-    if ((KIND != 0) && par != ((A.k - 1) & 1)) {
+    const int cand = kk & 1;                    // buffer this sweep writes (never the one an evaluating sweep reads)
+    if (!first && par != ((kk - 1) & 1)) {
         // the previous trial's candidate was rejected: the accepted point's block is in the other buffer
         const double *bp = A.blk + ((size_t)par * N + ii) * BLK;
         ha = bp[lane];
@@ -858,7 +830,6 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
                                 __builtin_amdgcn_readlane(__double2loint(v), src));
     };
 
-    long long seen = 0;                           // what this thread's accumulator adds fetched (tail flows wait for it)
     for (bool first_group = true;; first_group = false) {
     const int g_next = g + (int)gridDim.x;
     const bool last_group = !LOOP || g_next >= n_groups;   // workgroup-uniform
@@ -912,7 +883,9 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     }
     STAMP(3);
     d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-    for (int c0 = cbeg; c0 < cend; c0 += 64) {
+    // (SOLO: a wave without an image forms no rows -- it would only take the SIMD it shares from a wave that has one)
+    const int c_stop = (SOLO && !active) ? cbeg : cend;
+    for (int c0 = cbeg; c0 < c_stop; c0 += 64) {
         const int p = c0 + lane;
         const bool valid = p < cend;
         if (c0 > cbeg) {
@@ -962,7 +935,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     wave_lds_sync();
 
 
-    const bool work = WPI == 1 || leader;        // (wave-uniform) this wave carries the image beyond its Gram
+    const bool work = (WPI == 1 || leader) && (!SOLO || active);   // (wave-uniform) this wave carries the image beyond its Gram
     if (A.gram_out != nullptr && active && work) {
 #pragma unroll
         for (int r = 0; r < 4; r++) A.gram_out[(size_t)ii * 256 + lane + 64 * r] = Gs[lane + 64 * r];
@@ -976,7 +949,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     const int yj = lane < 10 ? lane : 9;
     double y[6];
 #ifdef CCAL_EXP_SKIP_C             // timing experiment only (wrong results): what the 6 x 6 factor and the Schur outputs cost a launch
-    if (work && A.k > 1000) {
+    if (work && kk > 1000) {
 #else
     if (work) {
 #endif
@@ -1043,21 +1016,47 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     STAMP(22);
     __syncthreads();
     STAMP(23);
-    if (tid < NRED) {
+    if constexpr (SOLO) {
+        // the sums of the launch-per-trial form's four-image workgroups, each in wave order, added up exactly and decoded: what
+        // the next prologue would have read from the accumulators, bit for bit -- straight into s_rs / s_S for the next pass
+        double v = 0.0;
+        int fl = 0;
+        if (tid < NRED) {
+            double pp[SOLO_WAVES / WAVES];
+#pragma unroll
+            for (int gq = 0; gq < SOLO_WAVES / WAVES; gq++) {
+                double sg = s_red[gq * WAVES * NRED + tid];
+#pragma unroll
+                for (int w = 1; w < WAVES; w++) sg += s_red[(gq * WAVES + w) * NRED + tid];
+                pp[gq] = sg;
+            }
+            v = acc_sum_local(pp, fl);
+        }
+        const int any_nan = __syncthreads_or(fl & 1), any_big = __syncthreads_or(fl & 2);
+        if (tid < NRED) {
+            if (tid == ACC_FLAG_COL) v = 0.0;
+            if (tid == RED_ERR) {
+                if (any_big) v = __longlong_as_double(0x7ff0000000000000ll);
+                if (any_nan) v = __longlong_as_double(0x7ff8000000000000ll);
+            }
+            s_rs[tid] = v;
+            if (tid < RED_DA) { s_S[oa * SROW + ob] = v; s_S[ob * SROW + oa] = v; }   // (tid == lane of wave 0)
+        }
+    } else if (tid < NRED) {
         double s = s_red[tid];
 #pragma unroll
         for (int w = 1; w < WAVES; w++) s += s_red[w * NRED + tid];   // fixed order inside the workgroup
         // ... and exact, order-independent across workgroups: limbs added with integer atomics
         // (replica = workgroup index mod R: with R = 8 and round-robin dispatch that is the workgroup's XCD, so one
         //  replica is only ever added to through one L2 -- choosing it from HW_REG_XCC_ID instead measured the same)
-        seen = acc_add(A.acc + ((size_t)(A.k % 3) * A.R + (blockIdx.x & (A.R - 1))) * ACC_ROW, tid, s);
+        acc_add(A.acc + ((size_t)(kk % 3) * A.R + (blockIdx.x & (A.R - 1))) * ACC_ROW, tid, s);
     }
     }
     STAMP(9);
 
     // ---- U = L^-T Y and this image's block for the next sweep's back-substitution ----
 #ifdef CCAL_EXP_SKIP_C
-    if (work && A.k > 1000) {
+    if (work && kk > 1000) {
 #else
     if (work) {
 #endif
@@ -1077,7 +1076,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     if (active) {
         double *bo = A.blk + ((size_t)cand * N + ii) * BLK;
 #ifdef CCAL_EXP_NO_BLOCK           // timing experiment only (wrong results): what the block stores add to the launch boundary
-        if (A.k > 1000) { bo[lane] = Hs[lane]; bo[64 + lane] = Hs[64 + lane]; }
+        if (kk > 1000) { bo[lane] = Hs[lane]; bo[64 + lane] = Hs[64 + lane]; }
 #else
         bo[lane] = Hs[lane];
         bo[64 + lane] = Hs[64 + lane];
@@ -1092,7 +1091,7 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     active = img_i < N;
     ii = active ? img_i : N - 1;
     img2 = reinterpret_cast<const float2 *>(A.img) + (size_t)ii * P;
-    if ((KIND == 0)) {
+    if (first) {
         hb = (lane >= BLK_EXT - 64 && lane < BLK_EXT - 64 + 6) ? A.ext0[(size_t)ii * A.ext0_stride + lane - (BLK_EXT - 64)] : 0.0;
     } else {
         const double *bp = A.blk + ((size_t)par * N + ii) * BLK;
@@ -1104,61 +1103,14 @@ __global__ __launch_bounds__(WAVES * 64, CCAL_TRIAL_MIN_WAVES) void k_lm_trial(c
     wave_lds_sync();                              // the block has left LDS: the next group's tile may overwrite it
     }
     STAMP(10);
-    if constexpr (TAIL) {
-        // ---- 5. tail: this workgroup's adds have been performed -> report; workgroup 0 advances the state machine ONCE ----
-        acc_wait(seen);
-        __syncthreads();                          // every adding thread of the workgroup has its fetched values back
-        if (tid == 0)
-            __hip_atomic_fetch_add(A.tail_cnt + (blockIdx.x & (TAIL_CNT - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (blockIdx.x != 0) return;
-        if (wave == 0) {
-            const bool all_in = tail_wait_all(A.tail_cnt, lane, gridDim.x);
-            __hip_atomic_store(A.tail_cnt + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
-            if (lane == 0) s_tail_ok = all_in ? 1 : 0;
-        }
-        __syncthreads();
-        const long long *acc_k = A.acc + (size_t)(A.k % 3) * acc_buf;
-        AccRegs qt;
-        acc_read_issue_sc1(acc_k, A.R, tid, qt);
-        acc_read_stage<true>(acc_k, A.R, s_acc, tid, qt);
-        __syncthreads();
-        // the totals are in LDS: the buffer is zero again before the launch ends (plain stores: the next adds come after the
-        // kernel boundary, nothing reads it before)
-        acc_clear(A.acc + (size_t)(A.k % 3) * acc_buf, A.R, 1, tid);
-        if (tid < NRED) {
-            double v = acc_row_decode(s_acc, tid);
-            if (!s_tail_ok && tid == RED_ERR) v = __longlong_as_double(0x7ff8000000000000ll);   // a workgroup never reported: abort the solve
-            s_rs[tid] = v;
-            if (tid < RED_DA) { s_S[oa * SROW + ob] = v; s_S[ob * SROW + oa] = v; }   // (tid == lane of wave 0)
-        }
-        __syncthreads();
-        if constexpr (FLOW == FLOW_TAIL_XCHG) {
-            // the whole all-reduce of the image-sharded fit, by this one workgroup: row -> the peers' inboxes, their rows added in rank order
-            const unsigned int sq = s_seq;
-            p2p_exchange_rows(A.p2p, p2p_tag(sq, (unsigned)(A.k + 1)), p2p_slot(sq, (unsigned)(A.k + 1)), s_rs, s_all, NRED, tid, true);
-            if (tid < RED_DA) {
-                const double v = s_rs[tid];
-                s_S[oa * SROW + ob] = v;
-                s_S[ob * SROW + oa] = v;
-            }
-            __syncthreads();
-        }
-        if (wave == 0) {
-            lm_advance_wave<true, false>(&ls, s_rs, s_S, A.trace, lane, A.k + 1);
-            if (!s_tail_ok) { ls.status = -6; ls.done = 1; }    // (host: CCAL_E_DEVICE, accumulators and counters re-zeroed)
-        }
-        __syncthreads();
-        LmState *nxt = A.st + ((A.k + 1) & 1);
-        if (tid < STATE_WORDS) reinterpret_cast<double *>(nxt)[tid] = reinterpret_cast<const double *>(&ls)[tid];
-        if (A.host_progress != nullptr && tid < 64) {
-            if (ls.done != 0 && A.host_result != nullptr && tid < HOST_WORDS)
-                reinterpret_cast<double *>(A.host_result)[tid] = reinterpret_cast<const double *>(&ls)[tid];
-            if (tid == 0) {
-                const unsigned long long word = ((unsigned long long)(unsigned)ls.trials << 32) | (ls.done ? 1ull : 0ull);
-                if (ls.done) __hip_atomic_store(A.host_progress, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                else __hip_atomic_store(A.host_progress, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
+    if constexpr (SOLO) __syncthreads();          // s_rs / s_S complete; every wave has consumed this pass's state
+    return true;
+    };
+    if constexpr (SOLO) {
+        if (trial(std::true_type(), 0))
+            for (int kk = 1; trial(std::false_type(), kk); kk++) {}
+    } else {
+        trial(std::integral_constant<bool, KIND == 0>(), A.k);
     }
     STAMP_RT(31);
     WG_TIME(2);
@@ -1281,19 +1233,27 @@ hipError_t launch_acc_debug(hipStream_t stream, const double *vals, int n_rows, 
 // launch wrappers
 // ---------------------------------------------------------------------------------------
 int lm_sweep_blocks(int N) { return (N + WAVES - 1) / WAVES; }
+int lm_solo_max_images() { return SOLO_WAVES; }
+// which k_lm_trial<FLOW, LOOP, KIND, WPI, SOLO> a sweep of N images launches (ccal_stats.sweep_form): FLOW | LOOP << 4 | WPI << 8 | SOLO << 12
+int lm_sweep_form(int N, int wpi, bool xchg, bool solo) {
+    if (solo) return 1 << 8 | 1 << 12;
+    const int groups = wpi == 1 ? lm_sweep_blocks(N) : (N * wpi + WAVES - 1) / WAVES;
+    return (xchg ? 1 : 0) | (groups > lm_max_grid() ? 1 << 4 : 0) | wpi << 8;
+}
 
-// Waves per image of the sweep (k_lm_trial's WPI): boards of more than 64 corners are split over 4 or 2 waves as long as
-// the split grid still is at most ONE workgroup per compute unit: every wave repeats the image's pose and rotation, so
-// beyond that the extra waves cost the SIMDs they share more than the shorter chain returns (15 x 10 corners, launch
-// duration in a solve, wpi 1 / 2 / 4 -- 100 images: 10.6 / 9.4 / 8.2 us; 500: 11.0 / 10.3 / 11.4; 1000: 12.9 / 12.9 / 12.9:
-// profiles/r04_pass_parallel_probe.txt).  CCAL_WPI = 1 / 2 / 4 forces a value for experiments, CCAL_WPI_CAP the grid limit.
+// Waves per image of the sweep (k_lm_trial's WPI), decided ONCE per problem (ccal_set_problem keeps it in the context: the Gram
+// of a split image is summed in another order, so the bits of a fit are a function of (device, N, P) -- and of nothing that could
+// change between two launches of one solve).  Measured rules:
+//  * boards of more than 64 corners (several 64-corner passes) are split over 4 or 2 waves as long as the split grid still is at
+//    most ONE workgroup per compute unit: every wave repeats the image's pose and rotation, so beyond that the extra waves cost
+//    the SIMDs they share more than the shorter chain returns (15 x 10 corners, launch duration in a solve, wpi 1 / 2 / 4 -- 100
+//    images: 10.6 / 9.4 / 8.2 us; 500: 11.0 / 10.3 / 11.4; 1000: 12.9 / 12.9 / 12.9: profiles/r04_pass_parallel_probe.txt; with
+//    three or four waves per SIMD resident, round 5, the 1250-image share gains 0.4 us: profiles/r05_role_split_probe.txt);
+//  * boards of ONE pass (9 x 6 corners: 28 matrix instructions become 8) are split over 4 waves while the split grid is at most
+//    one workgroup per TWO compute units: 100 images 7.2 -> 6.9 us per launch, 24.5 -> 23.7 us per solve; 250 images even, 500
+//    and more slower (8.2 -> 10.4 us); two waves return nothing at any size (profiles/r05_wpi_small_board_probe.txt).
+// CCAL_WPI = 1 / 2 / 4 forces a value, CCAL_WPI_CAP the grid limit, CCAL_WPI_MINP the smallest board that is split (experiments).
 int lm_waves_per_image(int N, int P, bool fused) {
-    int min_p = 65;                               // boards of one 64-corner pass stay one wave per image (CCAL_WPI_MINP: experiments)
-    if (const char *e = getenv("CCAL_WPI_MINP")) {
-        const int v = atoi(e);
-        if (v >= 8) min_p = v;
-    }
-    if (P < min_p) return 1;
     static int cus[16] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
@@ -1303,8 +1263,15 @@ int lm_waves_per_image(int N, int P, bool fused) {
         (void)hipGetLastError();
         cus[dev] = n;
     }
-    int cap = std::min(cus[dev], lm_max_grid());
-    (void)fused;                                  // (the fused exchange's 320-workgroup limit lies above the cap)
+    (void)fused;                                  // (the fused exchange's 320-workgroup limit lies above both caps)
+    int min_p = 16;
+    if (const char *e = getenv("CCAL_WPI_MINP")) {
+        const int v = atoi(e);
+        if (v >= 8) min_p = v;
+    }
+    if (P < min_p) return 1;
+    const bool one_pass = P <= 64;
+    int cap = std::min(one_pass ? cus[dev] / 2 : cus[dev], lm_max_grid());
     int want = 4;
     if (const char *e = getenv("CCAL_WPI")) {
         const int v = atoi(e);
@@ -1314,8 +1281,10 @@ int lm_waves_per_image(int N, int P, bool fused) {
         const int v = atoi(e);
         if (v > 0) cap = std::min(v, lm_max_grid());
     }
-    for (int w = want; w > 1; w /= 2)
+    for (int w = want; w > 1; w /= 2) {
+        if (one_pass && w == 2 && want != 2) break;   // (a one-pass board gains nothing from two waves)
         if (((long long)N * w + WAVES - 1) / WAVES <= cap) return w;
+    }
     return 1;
 }
 
@@ -1347,18 +1316,20 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     a.init = t.init; a.gram_out = t.gram_out; a.N = t.N; a.P = t.P; a.k = t.k; a.first = t.first;
     a.final_only = t.final_only;
     a.xchg_fused = 0;
-    a.tail_cnt = t.tail_cnt;
+    a.max_trials = t.max_trials;
     a.init_fail = t.init_fail; a.host_init_intr = t.host_init_intr; a.host_init_fail = t.host_init_fail;
     memset(&a.p2p, 0, sizeof a.p2p);
-    const bool tail = t.tail != 0;
-    if (tail && (t.final_only || t.row_in != nullptr || t.tail_cnt == nullptr)) return hipErrorInvalidValue;
-#ifndef CCAL_EXP_TAIL
-    // The tail-advance flows are an experiment (profiles/r04_tail_advance_probe.txt: +3.7 us per launch on C3 against the
-    // prologue form; built by tools/variants.py tail=CCAL_EXP_TAIL): the shipped library does not carry their kernels.
-    if (tail) return hipErrorInvalidValue;
-#endif
+    if (t.solo) {
+        // every trial of the solve in ONE launch of one workgroup (a few images on one GPU: no accumulators, no row, no exchange)
+        if (t.N > SOLO_WAVES || t.final_only || t.row_in != nullptr || t.p2p != nullptr || t.k != 0 || t.max_trials < 1) return hipErrorInvalidValue;
+        if (t.ev_start != nullptr && t.ev_stop != nullptr)
+            hipExtLaunchKernelGGL((k_lm_trial<FLOW_PRO, false, 1, 1, true>), dim3(1), dim3(SOLO_WAVES * 64), 0, stream, t.ev_start, t.ev_stop, 0, a);
+        else
+            hipLaunchKernelGGL((k_lm_trial<FLOW_PRO, false, 1, 1, true>), dim3(1), dim3(SOLO_WAVES * 64), 0, stream, a);
+        return hipGetLastError();
+    }
     // sweep grid: one workgroup per four images up to what the chip keeps resident; beyond that the workgroups loop
-    const int wpi = t.final_only ? 1 : lm_waves_per_image(t.N, t.P, t.p2p != nullptr && t.xchg_fused);
+    const int wpi = t.final_only ? 1 : (t.wpi == 1 || t.wpi == 2 || t.wpi == 4 ? t.wpi : lm_waves_per_image(t.N, t.P, t.p2p != nullptr && t.xchg_fused));
     const int groups = wpi == 1 ? lm_sweep_blocks(t.N) : (t.N * wpi + WAVES - 1) / WAVES;
     const int grid = t.final_only ? 1 : std::min(groups, lm_max_grid());
     const bool loop = !t.final_only && grid < groups;
@@ -1370,8 +1341,7 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     };
     auto pick = [&](auto flow) {
         constexpr int X = decltype(flow)::value;
-        if constexpr (X < FLOW_TAIL) { if (t.final_only) { launch(k_lm_trial<X, false, 2>); return; } }
-        if (t.final_only) return;
+        if (t.final_only) launch(k_lm_trial<X, false, 2>);
         else if (wpi == 4) { if (t.first) launch(k_lm_trial<X, false, 0, 4>); else launch(k_lm_trial<X, false, 1, 4>); }
         else if (wpi == 2) { if (t.first) launch(k_lm_trial<X, false, 0, 2>); else launch(k_lm_trial<X, false, 1, 2>); }
         else if (t.first) { if (loop) launch(k_lm_trial<X, true, 0>); else launch(k_lm_trial<X, false, 0>); }
@@ -1380,16 +1350,7 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     if (t.p2p != nullptr) {
         a.p2p = *t.p2p;
         a.xchg_fused = t.xchg_fused;
-#ifdef CCAL_EXP_TAIL
-        if (tail && t.xchg_fused) pick(std::integral_constant<int, FLOW_TAIL_XCHG>());
-        else if (tail) return hipErrorInvalidValue;   // (an exchanging fit without the fused exchange goes through row_in)
-        else
-#endif
         pick(std::integral_constant<int, FLOW_PRO_XCHG>());
-#ifdef CCAL_EXP_TAIL
-    } else if (tail) {
-        pick(std::integral_constant<int, FLOW_TAIL>());
-#endif
     } else {
         pick(std::integral_constant<int, FLOW_PRO>());
     }

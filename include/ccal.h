@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CCAL_VERSION 102 /* 0.1.2: ccal_p2p_export2 / ccal_p2p_connect2 (device id inside the blob), ccal_p2p_set_exchange mode 2 */
+#define CCAL_VERSION 103 /* 0.1.3: ccal_stats.sweep_form (was padding); 0.1.2: ccal_p2p_export2 / ccal_p2p_connect2, ccal_p2p_set_exchange mode 2 */
 
 /* status codes */
 #define CCAL_OK            0
@@ -76,7 +76,8 @@ typedef struct ccal_stats {
     int32_t lambda_lg10;   /* final log10(lambda) */
     int32_t n_bad;         /* images whose 6x6 block was not positive definite in the last sweep */
     int32_t timed_sweeps;  /* sweeps covered by sweep_us (0 unless ccal_set_sweep_timing is on) */
-    int32_t pad_;
+    int32_t sweep_form;    /* which instantiation k_lm_trial<FLOW, LOOP, KIND, WPI, SOLO> swept: FLOW | LOOP << 4 | WPI << 8 | SOLO << 12
+                            * (FLOW 1 = row exchange fused in, LOOP = looping grid, WPI = waves per image, SOLO = every trial in one launch) */
     double sweep_us;       /* mean device time of the sweep kernel, HIP events on the launch stream */
     double solve_kernels_us; /* device time of ALL launches of the solve (every trial + the terminating one), summed;
                               * 0 unless ccal_set_sweep_timing is on */

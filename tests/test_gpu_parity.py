@@ -1238,3 +1238,27 @@ def test_one_pipeline_fit_equals_the_stages_bit_for_bit(name, n):
     assert r_st["rms"] == r_pl["rms"] and r_st["iters"] == r_pl["iters"]
     for k in ("intr", "rvecs", "tvecs"):
         assert np.array_equal(r_st[k], r_pl[k]), k
+
+
+@pytest.mark.parametrize("name,n,crit", [("REF", 4, REF), ("C1", 3, TIGHT), ("C2", 4, TIGHT), ("C5", 3, REF), ("C2", 1, REF), ("REF", 6, REF)])
+def test_one_launch_solve_equals_the_launch_per_trial_form_bit_for_bit(name, n, crit, monkeypatch):
+    """Fits of at most four images on one GPU run every LM trial in ONE launch of one workgroup (k_lm_trial<.., SOLO>: the sums
+    of a trial stay in LDS and are added up the way the exact accumulators add the workgroups' sums).  Same decisions, same bits
+    as one launch per trial (CCAL_NO_SOLO=1; multi-pass boards with one wave per image there too, as the one-launch form sweeps
+    them), and the oracle's trajectory.  Six images: not eligible, both arms run the same launches."""
+    wl = syn.named_workload(name, n_images=n)
+    monkeypatch.setenv("CCAL_WPI", "1")
+    out = []
+    for no_solo in ("0", "1"):
+        monkeypatch.setenv("CCAL_NO_SOLO", no_solo)
+        with _solver(wl, crit) as s:
+            st, r = s.calibrate()
+            assert st in (0, 1)
+            out.append((r, s.trace()))
+    (a, ta), (b, tb) = out
+    assert a["iters"] == b["iters"] and a["sweeps"] == b["sweeps"] and a["rejected"] == b["rejected"]
+    assert np.array_equal(a["intr"], b["intr"]) and np.array_equal(a["rvecs"], b["rvecs"]) and np.array_equal(a["tvecs"], b["tvecs"])
+    assert a["rms"] == b["rms"] and a["final_err"] == b["final_err"]
+    assert len(ta) == len(tb) and all(x == y for x, y in zip(ta, tb))
+    ro = _oracle(wl, crit)
+    assert a["iters"] == ro["iters"] and abs(a["rms"] - ro["rms"]) < 1e-8
