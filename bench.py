@@ -235,13 +235,13 @@ def detect_block(with_cpu=True, reps=10):
     from PIL import Image
 
     from cameracalibrations_amd.detect import detect_corners
-    from oracle import detect_oracle as D
     ex = json.load(open(os.path.join(ROOT, "tests", "golden", "example_corners.json")))
     nc = tuple(ex["n_corners"])
     cases = [(np.ascontiguousarray(np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "example_png", f)))), nc,
               np.array(t, dtype=np.float64)) for f, t in zip(ex["files"], ex["corners"])]
+    from cameracalibrations_amd.synthetic import generate_checkerboard
     for w, h, ratio in ((13, 14, 95), (7, 10, 60)):
-        xys, img = D.generate_checkerboard((w, h), ratio)
+        xys, img = generate_checkerboard((w, h), ratio)
         cases.append((np.ascontiguousarray(img.astype(np.uint8)), (w, h), xys))
     out = {"images": len(cases), "pixels": int(sum(im.size for im, _, _ in cases)), "stat": "median over %d passes over the images" % reps,
            "what": "ccal_detect_corners per image, host buffer in, corners out (PCIe inclusive)"}
@@ -261,12 +261,91 @@ def detect_block(with_cpu=True, reps=10):
     out["images_per_s"] = len(cases) / float(np.median(ts))
     out["pixels_per_s"] = out["pixels"] / float(np.median(ts))
     if with_cpu:
+        from oracle import detect_oracle as D      # (the CPU comparison only)
         t0 = time.perf_counter()
         ro = [D.detect_corners(im, n) for im, n, _ in cases[:3]]
         out["cpu_images_per_s"] = 3 / (time.perf_counter() - t0)
         out["cpu"] = "oracle/detect_oracle.py (numpy, one thread), first 3 images"
         out["vs_cpu_max_abs_px"] = max(float(np.abs(detect_corners(im, n).transpose(1, 0, 2).reshape(-1, 2) - r).max())
                                        for (im, n, _), r in zip(cases[:3], ro))
+    return out
+
+
+def small_block(job, name, n_images, criteria, with_cpu=True):
+    """a small fit on one GPU (BASELINE.json configs[1]: 100 x 9x6 pinhole) with the same quantities as the headline"""
+    from cameracalibrations_amd import synthetic as syn
+    wl = syn.named_workload(name, n_images=n_images)
+    s, _, _ = job.make_solver(wl, wl.img, wl.n_images, criteria)
+    steps = 100
+    el, r = job.timed_solves(s, steps, 10)
+    us, n, b2b, _ = job.launch_timing(s, 30)
+    s.fit()
+    ts = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        s.fit()
+        ts.append(time.perf_counter() - t0)
+    out = {"workload": f"{wl.name}: {wl.n_images} images x {wl.n_corners[0]}x{wl.n_corners[1]} corners, {free_intrinsics(wl.flags)} free intrinsics",
+           "value": float(wl.n_images) * wl.n_points * r["sweeps"] * steps / el, "unit": "corner-residuals/s",
+           "ms_per_step": 1e3 * el / steps, "steps": steps, "full_fit_ms": 1e3 * float(np.median(ts)),
+           "avg_launch_us": us, "median_launch_us": job.median_launch_us, "launches_timed": n, "avg_launch_us_back_to_back": b2b,
+           "kernel": kernel_name(job.sweep_form), "lm": lm_block(r)}
+    s.close()
+    if with_cpu:
+        from oracle import oracle as orc
+        cores = max(1, min(16, len(os.sched_getaffinity(0))))
+        ro = [orc.calibrate(wl.obj, wl.img, wl.image_size, aspect=wl.aspect, flags=wl.flags, max_iter=criteria[0], eps=criteria[1],
+                            solver="schur", nthreads=cores) for _ in range(5)]
+        out["cpu_oracle"] = {"lm_ms": 1e3 * float(np.median([q["t_lm_s"] for q in ro])), "cores": cores, "kind": "port",
+                             "what": "oracle Schur mode, LM loop only, median of 5", "rms_px": ro[-1]["rms"], "iters": int(ro[-1]["iters"])}
+    return out
+
+
+def ref_example_block(with_cpu=True):
+    """The reference's own regime: its example's six images x 5x8 corners (test/example/corners.json -> tests/golden) through the
+    drop-in seam fit_model(sz, objpoints, imgpointss, n_corners, with_distortion, aspect) (src/detect_fit.jl:27-61), host arrays in
+    and out like the Julia caller's; and the same corners resident, as one pipeline."""
+    import cameracalibrations_amd as cc
+    from cameracalibrations_amd.solver import Solver, reference_flags
+    ex = json.load(open(os.path.join(ROOT, "tests", "golden", "example_corners.json")))
+    img = [np.array(m, dtype=np.float64) for m in ex["corners"]]
+    obj = cc.board_template(ex["n_corners"])
+
+    def med(fn, n):
+        fn()
+        fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t0)
+        return 1e3 * float(np.median(ts)), r
+    ms, m = med(lambda: cc.fit_model(ex["image_size_wh"], obj, img, ex["n_corners"], True, 1), 50)
+    out = {"workload": "test/example/corners.json: 6 images x 5x8 corners, reference flag word (K = 4: f, cx, cy, k1), criteria (30, 1e-3)",
+           "full_fit_ms": ms, "what": "fit_model(...) per call, host lists in / NamedTuple-like out, median of 50 (PCIe and Python inclusive)",
+           "rms_px": float(m.stats["rms"]), "iters": int(m.stats["iters"]), "sweeps": int(m.stats["sweeps"])}
+    arr = np.ascontiguousarray(np.stack(img), dtype=np.float32)
+    with Solver(0) as s:
+        s.set_problem(obj, len(img), ex["image_size_wh"], aspect=1.0, flags=reference_flags(True), max_iter=30, eps=1e-3)
+        s.set_image_points(arr)
+        ms_res, _ = med(lambda: s.fit(), 50)
+        s.init_intrinsics()
+        s.init_extrinsics()
+        ms_lm, _ = med(lambda: s.lm_run(), 100)
+        rr = s.result()
+        out.update({"full_fit_resident_ms": ms_res, "ms_per_step": ms_lm, "kernel": kernel_name(rr["sweep_form"]),
+                    "resident": "the same corners resident in HBM: ccal_fit (A4-A9 as one pipeline) per call | ccal_lm_run per call"})
+    if with_cpu:
+        from oracle import oracle as orc
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ro = orc.calibrate(obj, arr, ex["image_size_wh"], aspect=1.0, flags=reference_flags(True), max_iter=30, eps=1e-3,
+                               solver="dense", nthreads=1)
+            ts.append(time.perf_counter() - t0)
+        out["cpu_oracle"] = {"full_fit_ms": 1e3 * float(np.median(ts)), "lm_ms": 1e3 * ro["t_lm_s"], "cores": 1, "kind": "port",
+                             "what": "oracle, OpenCV-faithful dense mode incl. its initialisation, one thread, median of 5",
+                             "rms_px": ro["rms"], "iters": int(ro["iters"])}
     return out
 
 
@@ -532,16 +611,22 @@ class Job:
         the launch stream) and of back-to-back first-trial launches"""
         def timed():
             s.set_sweep_timing(True)
-            us, n_timed, t1, self.solve_kernels_us = 0.0, 0, time.perf_counter(), 0.0
+            us, n_timed, t1, self.solve_kernels_us, per_solve = 0.0, 0, time.perf_counter(), 0.0, []
             for _ in range(steps):
                 s.lm_run()
                 rr = s.result()
                 us += rr["sweep_us"] * rr["timed_sweeps"]
                 n_timed += rr["timed_sweeps"]
+                if rr["timed_sweeps"]:
+                    per_solve.append(rr["sweep_us"])
                 self.solve_kernels_us += rr["solve_kernels_us"] / max(steps, 1)   # all launches of a solve, summed
+                self.sweep_form = rr["sweep_form"]
             self.torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             s.set_sweep_timing(False)
+            # (surplus launches that return at once and re-damping sweeps are not among the timed ones: ccal_lm_run counts only
+            #  the launches whose trial evaluated a point; the median is over the solves' own means)
+            self.median_launch_us = float(np.median(per_solve)) if per_solve else 0.0
             return us / max(n_timed, 1), n_timed, s.time_sweep(200), dt / max(steps, 1)
         return self.together(timed, "launch timing")
 
@@ -600,7 +685,13 @@ def latency_floor(P):
     return sum(terms.values()), terms
 
 
-def roofline_block(N_rank, P, K, sweep_us, n_timed, b2b_us, events_ms_per_step, kernel):
+def kernel_name(form, kind=1):
+    """the k_lm_trial instantiation as rocprofv3 prints it, from ccal_stats.sweep_form (FLOW | LOOP << 4 | WPI << 8 | SOLO << 12)"""
+    return "ccal::k_lm_trial<%d, %s, %d, %d, %s>" % (form & 15, "true" if (form >> 4) & 1 else "false", kind, (form >> 8) & 15,
+                                                     "true" if (form >> 12) & 1 else "false")
+
+
+def roofline_block(N_rank, P, K, sweep_us, n_timed, b2b_us, events_ms_per_step, kernel, median_us=None):
     """the dominant kernel against its ceilings: HBM (the contract's classification), FP64 and the latency floor"""
     alg_bytes = algorithmic_bytes_per_sweep(N_rank, P)
     achieved = alg_bytes / (sweep_us * 1e-6) / 1e9 if sweep_us > 0 else 0.0
@@ -612,7 +703,7 @@ def roofline_block(N_rank, P, K, sweep_us, n_timed, b2b_us, events_ms_per_step, 
            # SURVEY.md 8d diagnostic: the same sweep with the per-image blocks kept in HBM (this design: one
            # 1-KB block read for both parities and written once per image and sweep)
            "bytes_per_launch_with_blocks_in_hbm": alg_bytes + N_rank * 3 * 1024,
-           "avg_launch_us": sweep_us, "launches_timed": n_timed, "avg_launch_us_back_to_back": b2b_us,
+           "avg_launch_us": sweep_us, "median_launch_us": median_us, "launches_timed": n_timed, "avg_launch_us_back_to_back": b2b_us,
            "timed_region_with_events_ms_per_step": events_ms_per_step,
            "fp64_flop_per_launch": flops, "fp64_tflops": tflops, "fp64_peak_tflops": FP64_PEAK_TFLOPS,
            "fp64_frac": tflops / FP64_PEAK_TFLOPS}
@@ -813,8 +904,8 @@ def main():
             "lm": lm_block(r, rt, tight_ms),
             "init": {"intrinsics_ms": 1e3 * rf["t_init_intr_s"], "extrinsics_ms": 1e3 * rf["t_init_extr_s"], "full_fit_ms": fit_ms,
                      "full_fit_stage_by_stage_ms": staged_ms, "pose_init_mode": 1, "pose_init_mode_2": fast_init},
-            "roofline": roofline_block(N, P, K, sweep_us, n_timed, sweep_us_b2b, 1e3 * ev_s,
-                                       "ccal::k_lm_trial<%s, false, 1>" % ("true" if world > 1 else "false")),
+            "roofline": roofline_block(N, P, K, sweep_us, n_timed, sweep_us_b2b, 1e3 * ev_s, kernel_name(job.sweep_form),
+                                       job.median_launch_us),
             "parity": "device == oracle (CPU restatement of OpenCV 4.10 from the published algorithm) in tests/; no run of OpenCV "
                       "pins the trajectory (iters-to-tol) -- DESIGN.md section 2",
         }
@@ -856,8 +947,7 @@ def main():
                              "config": config_block(wl5, "full", 4, my5.shape[0], wl5.n_images, world, comm5, CRITERIA, True),
                              "lm": lm_block(r5),
                              "roofline": roofline_block(my5.shape[0], wl5.n_points, free_intrinsics(wl5.flags), us5, n5, b2b5,
-                                                        1e3 * ev5, "ccal::k_lm_trial<%s, %s, 1>" % ("true" if world > 1 else "false",
-                                                                                                 "true" if my5.shape[0] > 2048 else "false"))}
+                                                        1e3 * ev5, kernel_name(job.sweep_form), job.median_launch_us)}
             s5.close()
             del s5
             if world == 1 and args.c5_images is None:
@@ -868,7 +958,8 @@ def main():
                 el8, r8 = job.timed_solves(s8, st5, 3)
                 us8, n8, b2b8, _ = job.launch_timing(s8, min(st5, 10))
                 out["c5"]["share_at_8"] = {
-                    "images": int(my8.shape[0]), "corners_per_image": wl5.n_points, "avg_launch_us": us8, "launches_timed": n8,
+                    "images": int(my8.shape[0]), "corners_per_image": wl5.n_points, "avg_launch_us": us8, "median_launch_us": job.median_launch_us,
+                    "kernel": kernel_name(job.sweep_form), "launches_timed": n8,
                     "avg_launch_us_back_to_back": b2b8, "ms_per_step": 1e3 * el8 / st5, "sweeps_per_solve": int(r8["sweeps"]),
                     "whole_avg_launch_us": us5, "predicted_kernel_speedup": us5 / us8 if us8 > 0 else None,
                     "what": "k_lm_trial on rank 0's 1250-image shard as its own fit on one GPU (no exchange): whole / share bounds the "
@@ -900,6 +991,14 @@ def main():
         if rank == 0:
             out["transports"] = tb
     if extras and world == 1:
+        try:
+            out["c1"] = small_block(job, "C1", None, CRITERIA, with_cpu=not args.no_cpu_baseline)
+        except Exception as exc:      # noqa: BLE001
+            out["c1"] = {"error": str(exc)}
+        try:
+            out["ref_example"] = ref_example_block(with_cpu=not args.no_cpu_baseline)
+        except Exception as exc:      # noqa: BLE001
+            out["ref_example"] = {"error": str(exc)}
         try:
             out["maps"] = maps_block(wl, rf, with_cpu=not args.no_cpu_baseline)
         except Exception as exc:      # noqa: BLE001

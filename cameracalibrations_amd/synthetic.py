@@ -164,3 +164,18 @@ def named_workload(name, n_images=None, sigma=0.1, seed_offset=0):
     depth = (8.0, 16.0) if n_corners == (9, 6) else (14.0, 28.0)
     return make_workload(name, n_corners, n_images or N, model, _BASE_SEED + idx + seed_offset, sigma=sigma,
                          depth=depth)
+
+
+def generate_checkerboard(n_corners, n):
+    """An axis-aligned synthetic board of the shape the reference's detector tests render (test/runtests.jl:6-18: alternating
+    squares of n x n pixels with a one-square white border): -> expected RowCol corners (P, 2), image (rows, cols) in 0..255.
+    Input generator only (bench.py's `detect` block, tools/, tests); the detector itself never sees it."""
+    n1, n2 = n_corners
+    i = np.arange(1, n1 + 2)[:, None]
+    j = np.arange(1, n2 + 2)[None, :]
+    img = np.where(i % 2 == 1, j % 2 == 1, j % 2 == 0)
+    pad = np.ones((n1 + 3, n2 + 3), dtype=bool)
+    pad[1:-1, 1:-1] = img
+    imgl = np.kron(pad.astype(np.float64), np.ones((n, n)))
+    xys = np.array([(n * ii - 0.5, n * jj - 0.5) for jj in range(n2 + 1, 1, -1) for ii in range(n1 + 1, 1, -1)])
+    return xys, imgl * 255.0

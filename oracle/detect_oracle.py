@@ -246,16 +246,3 @@ def detect_corners(im, n_corners):
     pts = corner_subpix(im, pts)
     pts, resp = merge_close(pts, resp)
     return order_grid(pts, resp, n_corners[0], n_corners[1], im)
-
-
-def generate_checkerboard(n_corners, n):
-    """The reference's synthetic board (test/runtests.jl:6-18): -> expected corners (P,2), image."""
-    n1, n2 = n_corners
-    i = np.arange(1, n1 + 2)[:, None]
-    j = np.arange(1, n2 + 2)[None, :]
-    img = np.where(i % 2 == 1, j % 2 == 1, j % 2 == 0)
-    pad = np.ones((n1 + 3, n2 + 3), dtype=bool)
-    pad[1:-1, 1:-1] = img
-    imgl = np.kron(pad.astype(np.float64), np.ones((n, n)))
-    xys = np.array([(n * ii - 0.5, n * jj - 0.5) for jj in range(n2 + 1, 1, -1) for ii in range(n1 + 1, 1, -1)])
-    return xys, imgl * 255.0

@@ -13,6 +13,7 @@ import os
 import numpy as np
 import pytest
 
+from cameracalibrations_amd import synthetic as syn
 from oracle import detect_oracle as D
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,7 +37,7 @@ def test_oracle_real_images_within_one_pixel():
 
 @pytest.mark.parametrize("w,h,ratio", [(13, 14, 95), (14, 15, 100)])
 def test_oracle_synthetic_boards(w, h, ratio):
-    xys, img = D.generate_checkerboard((w, h), ratio)
+    xys, img = syn.generate_checkerboard((w, h), ratio)
     res = D.detect_corners(img, (w, h))
     assert res is not None and np.linalg.norm(res - xys, axis=1).max() < 1                # runtests.jl:26,40
 
@@ -89,7 +90,7 @@ def test_gpu_synthetic_boards_reference_loop():
             if (w % 2) == (h % 2):
                 continue
             for ratio in range(95, 101):
-                xys, img = D.generate_checkerboard((w, h), ratio)
+                xys, img = syn.generate_checkerboard((w, h), ratio)
                 res = detect_corners(img.astype(np.uint8), (w, h))
                 assert res is not None, (w, h, ratio)
                 flat = res.transpose(1, 0, 2).reshape(-1, 2)

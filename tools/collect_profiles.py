@@ -1,5 +1,5 @@
 """Copies what tools/profiles.sh <round> left under gpurun_out/ into profiles/ (tracked) and writes the per-instantiation
-kernel-trace summary.  usage: collect_profiles.py [round-prefix]   (default r03)"""
+kernel-trace summary.  usage: collect_profiles.py [round-prefix]   (default r05)"""
 import csv
 import json
 import os
@@ -8,9 +8,14 @@ import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
+
+
+def template_args(name):
+    """'void ccal::k_lm_trial<0, false, 1, 1, false>(ccal::TrialArgs)' -> ['0', 'false', '1', '1', 'false']"""
+    return [a.strip() for a in name.split("<", 1)[1].split(">", 1)[0].split(",")] if "<" in name else []
 
 
 def trace_summary(path):
@@ -21,10 +26,20 @@ def trace_summary(path):
             if "k_lm_trial" not in n:
                 continue
             by.setdefault(n, []).append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1000.0)
-            if n.endswith("1>(ccal::TrialArgs)"):
+            a = template_args(n)
+            if len(a) >= 3 and a[2] == "1":                    # a later trial: the instantiation the roofline is quoted on
                 meta = {"grid_threads": [int(row["Workgroup_Size_X"]), int(row["Grid_Size_X"])], "vgpr": row["VGPR_Count"],
                         "sgpr": row["SGPR_Count"], "lds_bytes": row["LDS_Block_Size"], "scratch": row["Scratch_Size"]}
-    out = {"by_kernel": {n: {"launches": len(v), "mean_us": statistics.fmean(v), "median_us": statistics.median(v)} for n, v in sorted(by.items())}}
+    out = {"by_kernel": {}}
+    for n, v in sorted(by.items()):
+        # A graph is sized for the trials the previous solve needed; a solve that ends earlier leaves SURPLUS launches that find
+        # `done` and return at once (a few us).  They are not sweeps: launches shorter than 60 % of the instantiation's median
+        # are counted apart and excluded from mean and median.
+        med0 = statistics.median(v)
+        full = [x for x in v if x >= 0.6 * med0]
+        out["by_kernel"][n] = {"launches": len(full), "mean_us": statistics.fmean(full), "median_us": statistics.median(full),
+                               "surplus_early_return_launches_excluded": len(v) - len(full),
+                               "mean_us_all_launches": statistics.fmean(v)}
     out.update(meta)
     return out
 
@@ -32,7 +47,7 @@ def trace_summary(path):
 runs = {"C3 1000x54 (bench.py --steps 50, as the driver runs it)": "c3", "C5 10000x150 on one GPU": "c5",
         "C5 per-GPU share at 8 GPUs (1250x150)": "c5shard"}
 summary = {"what": "rocprofv3 --kernel-trace of the commands in tools/profiles.sh: duration of ccal::k_lm_trial by instantiation "
-                   "<exchange, looping, kind> (kind 0 = first launch of a solve, 1 = later trial, 2 = terminating prologue-only launch)",
+                   "<FLOW, LOOP, KIND, WPI, SOLO> (KIND 0 = first launch of a solve, 1 = later trial, 2 = terminating prologue-only launch); surplus early-return launches excluded",
            "runs": {k: trace_summary(os.path.join(G, R + "_prof", d, "prof_kernel_trace.csv")) for k, d in runs.items()}}
 json.dump(summary, open(os.path.join(P, R + "_kernel_trace_summary.json"), "w"), indent=1)
 for src, dst in (("_prof/c3/prof_kernel_stats.csv", "_bench_kernel_stats.csv"), ("_prof/c5/prof_kernel_stats.csv", "_c5_kernel_stats.csv"),
@@ -46,4 +61,4 @@ for src, dst in (("pmc/summary.json", "_pmc_traffic_summary.json"), ("pmc_c5/sum
     if os.path.exists(os.path.join(G, src)):
         shutil.copy(os.path.join(G, src), os.path.join(P, R + dst))
 for k, v in summary["runs"].items():
-    print(k, {n.split("k_lm_trial")[1].split("(")[0]: round(d["mean_us"], 2) for n, d in v["by_kernel"].items()})
+    print(k, {n.split("k_lm_trial")[1].split("(")[0]: (round(d["mean_us"], 2), round(d["median_us"], 2)) for n, d in v["by_kernel"].items()})
