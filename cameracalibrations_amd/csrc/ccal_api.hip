@@ -32,6 +32,9 @@ namespace ccal { hipError_t debug_read_stamps(unsigned long long *out); hipError
 // workgroups (every one of them polls the inbox); beyond it one k_lm_exchange workgroup per trial does it.
 // Decided from the GLOBAL problem size so that every rank of a fit takes the same path.
 static constexpr int FUSED_XCHG_MAX_BLOCKS = 320;
+// the pinned staging block of a context (64 KB) as a small ccal_calibrate call divides it
+static constexpr size_t PIN_OBJ_OFF = 0, PIN_OBJ_BYTES = 8 * 1024, PIN_IMG_OFF = 8 * 1024, PIN_IMG_BYTES = 32 * 1024,
+                        PIN_POSE_OFF = 40 * 1024, PIN_POSE_BYTES = 23 * 1024;
 
 static constexpr size_t ACC_BYTES = sizeof(long long) * ACC_BUFS * ACC_MAX_REPLICAS * ACC_ROW;
 
@@ -120,7 +123,7 @@ struct ccal_ctx {
     // one solve = one replayable graph: begin + lm_batch x (sweep, solve) + state read-back
     hipGraphExec_t g_first = nullptr;
     struct GraphKey {             // everything baked into the captured launches
-        const void *obj, *img, *blk, *st, *acc, *red, *trace, *intr0, *ext0;
+        const void *obj, *img, *blk, *st, *acc, *red, *trace, *intr0, *ext0, *host_poses;
         int N, P, batch, R, wpi;
         LmInit init;
     } graph_key{};
@@ -129,6 +132,11 @@ struct ccal_ctx {
     int dbg_runs = 0;
     bool graph_dirty = true, use_graph = true, adaptive_batch = true, spin_wait = true;
     int wpi = 1;                  // waves per image of the sweep, resolved once per problem (lm_waves_per_image)
+    bool wpi_sharded = false;     // ... for a fit that was / was not image-sharded at that time (re-resolved when a transport is attached)
+    // small drop-in calls (ccal_calibrate): inputs staged in the pinned block and copied by a kernel, poses written to it by the launch
+    // that ends the solve -- no copy command, no read-back launch, one wait.  Layout of h_pin: template | corners | poses
+    bool small_call = false;
+    double *host_poses = nullptr;
     bool use_solo = true;         // fits of a few images on one GPU run all their trials in ONE launch (CCAL_NO_SOLO=1: launch per trial)
     bool run_solo = false;
     // a solve in flight (lm_begin .. lm_end)
@@ -156,6 +164,17 @@ static void free_problem_buffers(ccal_ctx *c) {
 extern "C" {
 
 int ccal_version(void) { return CCAL_VERSION; }
+
+static bool sharded(const ccal_ctx *c);
+// Waves per image of the sweep, once per problem (and again when a transport is attached: an image-sharded fit keeps one-pass
+// boards at one wave per image -- the split's 3 % are not worth four times as many workgroups polling a fused exchange)
+static void resolve_wpi(ccal_ctx *c) {
+    c->wpi_sharded = sharded(c);
+    if (c->P <= 0 || c->N <= 0) { c->wpi = 1; return; }
+    const int w = (c->wpi_sharded && c->P <= 64) ? 1 : lm_waves_per_image(c->N, c->P, c->wpi_sharded);
+    if (w != c->wpi) c->graph_dirty = true;
+    c->wpi = w;
+}
 const char *ccal_last_error(void) { return g_err.c_str(); }
 
 int ccal_device_count(void) {
@@ -447,13 +466,18 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
         c->n_cap = n;
         c->p_cap = P;
     }
-    HIPCHK(hipMemcpyAsync(c->d_obj, obj, sizeof(float) * 3 * P, hipMemcpyHostToDevice, c->stream));
+    if (c->small_call && sizeof(float) * 3 * P <= PIN_OBJ_BYTES) {
+        memcpy(static_cast<char *>(c->h_pin) + PIN_OBJ_OFF, obj, sizeof(float) * 3 * P);
+        HIPCHK(launch_copy_words(c->stream, static_cast<char *>(c->h_pin) + PIN_OBJ_OFF, c->d_obj, (size_t)3 * P));
+    } else {
+        HIPCHK(hipMemcpyAsync(c->d_obj, obj, sizeof(float) * 3 * P, hipMemcpyHostToDevice, c->stream));
+    }
     // (no clearing of blk / ext0: a solve's first launch reads the six pose words of ext0 and nothing of blk, and every sweep
     //  writes its images' blocks whole -- two memset launches per call were a tenth of a reference-sized fit)
     if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));   // `obj` may be released by the caller after return
     c->P = P; c->N = N; c->width = width; c->height = height; c->aspect = aspect; c->flags = flags;
     c->max_iter = max_iter; c->eps = eps;
-    c->wpi = lm_waves_per_image(N, P, false);
+    resolve_wpi(c);
     const int sweep_grid = std::min(lm_sweep_blocks(N), lm_max_grid());
     const int old_R = c->acc_R;
     c->acc_R = lm_acc_replicas(sweep_grid);
@@ -485,7 +509,12 @@ int ccal_set_image_points(ccal_ctx *c, const float *img_host) {
         HIPCHK(hipMalloc(&c->d_img_own, need));
         c->img_cap = need;
     }
-    HIPCHK(hipMemcpyAsync(c->d_img_own, img_host, need, hipMemcpyHostToDevice, c->stream));
+    if (c->small_call && need <= PIN_IMG_BYTES) {
+        memcpy(static_cast<char *>(c->h_pin) + PIN_IMG_OFF, img_host, need);
+        HIPCHK(launch_copy_words(c->stream, static_cast<char *>(c->h_pin) + PIN_IMG_OFF, c->d_img_own, need / 4));
+    } else {
+        HIPCHK(hipMemcpyAsync(c->d_img_own, img_host, need, hipMemcpyHostToDevice, c->stream));
+    }
     if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));
     c->d_img = c->d_img_own;
     c->have_img = true;
@@ -784,6 +813,7 @@ static TrialLaunch base_launch(ccal_ctx *c) {
     t.intr0 = c->d_intr0; t.ext0 = c->d_ext0; t.ext0_stride = EXT; t.init = make_init(c);
     t.N = c->N; t.P = c->P; t.wpi = c->wpi;
     // the first launch of every solve reports the initialisation's flags and start intrinsics to the host (finish_init_check)
+    t.host_poses = c->host_poses;
     t.init_fail = c->d_fail; t.host_init_intr = reinterpret_cast<double *>(c->h_flags + 4); t.host_init_fail = c->h_flags;
     return t;
 }
@@ -873,6 +903,7 @@ static int lm_prepare(ccal_ctx *c) {
     if (!c->have_problem || !c->have_img || !c->have_intr || !c->have_ext)
         return fail(CCAL_E_STATE, "ccal_lm_run: initial intrinsics / extrinsics / image points not set");
     HIPCHK(hipSetDevice(c->device));
+    if (c->wpi_sharded != sharded(c)) resolve_wpi(c);   // a transport was attached or dropped since the problem was set
     c->run_t0 = now_s();
     // upper bound on trials: every accepted iteration may be preceded by lambda climbing
     // from -16 to 16 (rejections + re-damping sweeps)
@@ -916,7 +947,7 @@ static int lm_begin(ccal_ctx *c) {
         ccal_ctx::GraphKey key;
         memset(&key, 0, sizeof key);
         key.obj = c->d_obj; key.img = c->d_img; key.blk = c->d_blk; key.st = c->d_st; key.acc = c->d_acc; key.R = c->acc_R;
-        key.red = c->d_red; key.trace = c->d_trace; key.intr0 = c->d_intr0; key.ext0 = c->d_ext0;
+        key.red = c->d_red; key.trace = c->d_trace; key.intr0 = c->d_intr0; key.ext0 = c->d_ext0; key.host_poses = c->host_poses;
         key.N = c->N; key.P = c->P; key.wpi = c->wpi; key.batch = c->lm_batch; key.init = make_init(c);
         if (c->graph_dirty || !c->g_first || memcmp(&key, &c->graph_key, sizeof key) != 0) {
             const int rc = capture_graph(c, &c->g_first);
@@ -1177,6 +1208,12 @@ int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int
     int lm_rc = 0;
     const bool guess = (flags & CCAL_USE_INTRINSIC_GUESS) != 0;
     c->defer_sync = true;          // the whole pipeline is enqueued, then checked once
+    // A small call (the reference's own regime: a handful of images) stages its inputs in the context's pinned block, from where a
+    // kernel copies them (no copy commands from pageable memory), and has the launch that ends the solve write the poses back
+    // into the same block (no read-back launch, no second wait).
+    c->small_call = P >= 1 && N >= 1 && sizeof(float) * 3 * (size_t)P <= PIN_OBJ_BYTES && sizeof(float) * 2 * (size_t)P * N <= PIN_IMG_BYTES &&
+                    sizeof(double) * 8 * (size_t)N <= PIN_POSE_BYTES && !getenv("CCAL_NO_SMALL_CALL");
+    c->host_poses = (c->small_call && (rvecs || tvecs)) ? reinterpret_cast<double *>(static_cast<char *>(c->h_pin) + PIN_POSE_OFF) : nullptr;
     do {
         if ((rc = ccal_set_problem(c, obj, P, N, width, height, aspect, flags, max_iter, eps)) < 0) break;
         if ((rc = ccal_set_image_points(c, img)) < 0) break;
@@ -1192,10 +1229,14 @@ int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int
         // through pinned memory, and one wait on a completion word instead of two stream synchronisations.
         // (the initialisation's flags and values came to the host with the solve's first launch)
         const bool poses = lm_rc >= 0 && c->have_result && (rvecs || tvecs);
-        if (poses) {
+        const double *pose_rows = nullptr;
+        if (poses && c->host_poses != nullptr) {
+            pose_rows = c->host_poses;         // written by the launch that found the solve done, ahead of its progress word
+        } else if (poses) {
             if ((rc = stage_need(c, sizeof(double) * 8 * (size_t)c->N)) < 0) break;
             if ((rc = enqueue_pose_rows(c, static_cast<double *>(c->h_stage))) < 0) break;
             if ((rc = signal_and_spin(c)) < 0) break;
+            pose_rows = static_cast<const double *>(c->h_stage);
         } else if (lm_rc < 0) {
             // the LM may not have got as far as its first launch, let alone waiting for its completion: fetch the flags the old way
             (void)finish_init_enqueue(c);
@@ -1206,7 +1247,7 @@ int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int
         if ((rc = lm_rc) < 0) { g_err = lm_err; break; }
         ccal_stats st;
         if ((rc = ccal_get_result(c, intr, nullptr, nullptr, &st)) < 0) break;
-        if (poses) unpack_pose_rows(c, static_cast<const double *>(c->h_stage), rvecs, tvecs);
+        if (poses) unpack_pose_rows(c, pose_rows, rvecs, tvecs);
         if (K4) memcpy(K4, intr, sizeof(double) * 4);
         if (dist5) memcpy(dist5, intr + 4, sizeof(double) * 5);
         if (rms) *rms = st.rms;
@@ -1215,6 +1256,8 @@ int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int
         rc = lm_rc;
     } while (0);
     c->defer_sync = false;
+    c->small_call = false;
+    c->host_poses = nullptr;
     if (rc < 0) {                  // leave no half-finished work behind on the cached stream
         const std::string keep = g_err;
         (void)hipStreamSynchronize(c->stream);

@@ -35,6 +35,7 @@ struct TrialLaunch {              // one launch of k_lm_trial (see ccal_lm.hip)
     int wpi = 0;                  // waves per image as ccal_set_problem resolved it (lm_waves_per_image); 0: resolve at the launch
     int solo = 0;                 // one launch, one workgroup, every trial of the solve (N <= lm_solo_max_images(), single GPU; k = 0):
     int max_trials = 0;           // ... up to this many trials
+    double *host_poses = nullptr;       // pinned host memory [N][8]: the launch that finds the solve done writes the accepted poses there
     int *init_fail = nullptr;           // first launch: the init stages' four failure words (device; word 2 = "a pose stage has run since
                                         // the last report", cleared here) and the start intrinsics are
     double *host_init_intr = nullptr;   // copied to pinned host memory by workgroup 0 (all three set, or none)
@@ -92,6 +93,8 @@ hipError_t launch_map_forward(hipStream_t stream, const double *xyz, long long x
 hipError_t launch_map_inverse(hipStream_t stream, const double *rc, double *xyz, int M, int N, const MapIntr &in,
                               const double *rt);
 hipError_t launch_signal(hipStream_t stream, unsigned long long *flag, unsigned long long value);   // pinned completion word
+// n 32-bit words src -> dst by a kernel on `stream` (src: pinned, device-mapped host memory a small call staged its inputs in)
+hipError_t launch_copy_words(hipStream_t stream, const void *src, void *dst, size_t n_words);
 // intr[9], fail[4] (device) -> pinned host memory, by a kernel on `stream`
 hipError_t launch_init_readback(hipStream_t stream, const double *intr, const int *fail, double *host_intr, int *host_fail);
 struct RectPar { double v[16]; };   // f0 f1 c0 c1 k rvec(3) tvec(3) checker_size ratio index_offset, by value

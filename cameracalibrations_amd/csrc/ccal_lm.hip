@@ -501,6 +501,8 @@ struct TrialArgs {
     unsigned long long *host_progress;
     double *gram_out;
     LmInit init;
+    double *host_poses;           // != NULL: the launch that finds the solve done also writes the accepted poses there (pinned host
+                                  // memory, N rows of 8 doubles: rvec, tvec, 2 pad) -- a small drop-in call then needs no read-back
     int *init_fail;               // first launch of a solve, workgroup 0: the initialisation's failure words (device) ...
     double *host_init_intr;       // ... and the start intrinsics go to pinned host memory (a pipelined fit needs no read-back kernel)
     int *host_init_fail;
@@ -786,6 +788,17 @@ __global__ __launch_bounds__((SOLO ? SOLO_WAVES : WAVES) * 64, SOLO ? CCAL_SOLO_
     if (blockIdx.x == 0 && (!SOLO || ls.done || budget_out)) {
         LmState *cur = A.st + (kk & 1);
         if (tid < STATE_WORDS) reinterpret_cast<double *>(cur)[tid] = reinterpret_cast<const double *>(&ls)[tid];
+        if (ls.done && A.host_poses != nullptr) {
+            // the accepted poses, straight to pinned host memory ahead of the progress word (the blocks of every image were
+            // complete one kernel boundary -- SOLO: one barrier -- ago)
+            const double *bsrc = A.blk + (size_t)ls.parity * N * BLK + BLK_EXT;
+            for (int i = tid; i < N * 6; i += NW * 64) {
+                const int im = i / 6, w = i - 6 * im;
+                __hip_atomic_store(A.host_poses + (size_t)im * 8 + w, bsrc[(size_t)im * BLK + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            __threadfence_system();
+            __syncthreads();
+        }
         if (A.host_progress != nullptr && tid < 64) {
             // wave 0 alone talks to the host: the state header when the solve terminates, then the
             // progress word (trials << 32) | done that the host spins on, released at system scope
@@ -1317,6 +1330,7 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     a.final_only = t.final_only;
     a.xchg_fused = 0;
     a.max_trials = t.max_trials;
+    a.host_poses = t.host_poses;
     a.init_fail = t.init_fail; a.host_init_intr = t.host_init_intr; a.host_init_fail = t.host_init_fail;
     memset(&a.p2p, 0, sizeof a.p2p);
     if (t.solo) {

@@ -7,6 +7,8 @@
 // All FP64; one lane per point, coalesced [3,M] / [2,M] streams.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <cstdint>
 
 #include "ccal_kernels.hpp"
@@ -201,6 +203,17 @@ __global__ void k_init_readback(const double *__restrict__ intr, const int *__re
 }
 hipError_t launch_init_readback(hipStream_t stream, const double *intr, const int *fail, double *host_intr, int *host_fail) {
     hipLaunchKernelGGL(k_init_readback, dim3(1), dim3(64), 0, stream, intr, fail, host_intr, host_fail);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_copy_words(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+hipError_t launch_copy_words(hipStream_t stream, const void *src, void *dst, size_t n_words) {
+    if (n_words == 0) return hipSuccess;
+    const int grid = (int)std::min<size_t>((n_words + 255) / 256, 64);
+    hipLaunchKernelGGL(k_copy_words, dim3(grid), dim3(256), 0, stream, static_cast<const uint32_t *>(src), static_cast<uint32_t *>(dst), n_words);
     return hipGetLastError();
 }
 

@@ -332,16 +332,19 @@ def test_edge_cases():
     assert np.abs(m.Rs[0] - ro["rvecs"][0]).max() < 1e-6
 
 
-def test_allreduce_paths_world1():
+def test_allreduce_paths_world1(monkeypatch):
     """The multi-GPU code path (reduce kernel -> all-reduce -> solve kernel, no graph) with one
     rank: (a) torch.distributed hook (nccl == RCCL), (b) the library's own RCCL communicator,
-    (c) the direct xGMI exchange kernels.  All must reproduce the graph path bit for bit."""
+    (c) the direct xGMI exchange kernels.  All must reproduce the graph path bit for bit (the single-GPU fit with one wave per
+    image, as image-sharded fits sweep one-pass boards: a split image's Gram is summed in another order)."""
     import torch
     import torch.distributed as dist
     from cameracalibrations_amd.distributed import TorchAllReduce, allgather_bytes_via_torch, broadcast_id_via_torch
     wl = syn.named_workload("C2", n_images=37)
+    monkeypatch.setenv("CCAL_WPI", "1")
     with _solver(wl, REF) as s:
         _, base = s.calibrate()
+    monkeypatch.delenv("CCAL_WPI")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29533")
     torch.cuda.set_device(0)
