@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("CCAL_LIB") or os.path.join(_HERE, "libccal_hip.so")  
 NINTR = 9
 
 # status codes (include/ccal.h)
-OK, W_MAX_ITER = 0, 1
+OK, W_MAX_ITER, W_RANK_DEFICIENT = 0, 1, 2      # (the two warnings are bits: 3 = both)
 E_ARG, E_NONPLANAR, E_DEGENERATE, E_NONFINITE, E_DEVICE, E_COMM, E_STATE = -1, -2, -3, -4, -5, -6, -7
 
 # flag word (OpenCV values, reference src/detect_fit.jl:40)
@@ -110,6 +110,7 @@ SIGNATURES = {
                                       C.c_int32, _dp, C.POINTER(C.c_int32), _dp]),
     "ccal_debug_image_grams": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "ccal_debug_acc_sum": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32, _dp]),
+    "ccal_debug_get_homographies": (C.c_int, [C.c_void_p, _dp]),
     "ccal_debug_p2p_world": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, _dp, _dp]),
     "ccal_debug_multi_set_epoch": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.c_uint32]),
     "ccal_get_init": (C.c_int, [C.c_void_p, _dp, _dp]),

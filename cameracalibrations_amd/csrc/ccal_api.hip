@@ -1041,7 +1041,7 @@ static int lm_end(ccal_ctx *c) {
     }
     if (r.status == -4) return fail(CCAL_E_NONFINITE, "ccal_lm_run: non-finite reprojection error on the device");
     if (r.status == -3) return fail(CCAL_E_DEGENERATE, "ccal_lm_run: reduced intrinsic system not positive definite");
-    return r.status == 1 ? CCAL_W_MAX_ITER : CCAL_OK;
+    return (r.status == 1 ? CCAL_W_MAX_ITER : CCAL_OK) | (r.n_bad > 0 ? CCAL_W_RANK_DEFICIENT : 0);
 }
 
 int ccal_lm_run(ccal_ctx *c) {
@@ -1749,6 +1749,15 @@ int ccal_debug_multi_set_epoch(int32_t n_dev, const int32_t *dev_ids, uint32_t e
         return CCAL_OK;
     }
     return fail(CCAL_E_STATE, "ccal_debug_multi_set_epoch: no such device set on this thread (call ccal_calibrate_multi first)");
+}
+
+int ccal_debug_get_homographies(ccal_ctx *c, double *H_host) {
+    if (!c || !H_host) return fail(CCAL_E_ARG, "ccal_debug_get_homographies: NULL argument");
+    if (!c->have_problem || !c->have_H) return fail(CCAL_E_STATE, "ccal_debug_get_homographies: no intrinsics stage has run on these corners");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(H_host, c->d_H, sizeof(double) * 18 * (size_t)c->N, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return CCAL_OK;
 }
 
 int ccal_debug_acc_sum(ccal_ctx *c, const double *rows, int32_t n_rows, int32_t replicas, double out[68]) {

@@ -283,6 +283,19 @@ bool order_grid(const std::vector<P2> &pts, const std::vector<double> &resp, int
         d = std::sqrt(best);
         return q;
     };
+    // |gray difference| across the segment p -> p + v at its midpoint, a quarter of its length to either side: a lattice AXIS
+    // neighbour's segment runs along the edge between a dark and a bright square (large), a diagonal neighbour's through the
+    // middle of one square and a two-step neighbour's midpoint is itself a corner (both ~0).  (Python's round(): half to even)
+    auto px = [&](double qr, double qc) {
+        const int r = std::min(std::max((int)std::nearbyint(qr), 0), rows - 1), c = std::min(std::max((int)std::nearbyint(qc), 0), cols - 1);
+        return (double)gray[(long long)r * sr + (long long)c * sc];
+    };
+    auto edge_contrast = [&](const P2 &p, const P2 &v) {
+        const double ln = std::hypot(v.r, v.c);
+        const double nr = -v.c / ln, nc = v.r / ln;
+        const double mr = p.r + 0.5 * v.r, mc = p.c + 0.5 * v.c;
+        return std::fabs(px(mr + 0.25 * ln * nr, mc + 0.25 * ln * nc) - px(mr - 0.25 * ln * nr, mc - 0.25 * ln * nc));
+    };
     P2 mean{0, 0};
     for (auto &p : pts) { mean.r += p.r / M; mean.c += p.c / M; }
     std::vector<int> seeds(M);
@@ -294,17 +307,27 @@ bool order_grid(const std::vector<P2> &pts, const std::vector<double> &resp, int
         std::vector<int> nb(M);
         for (int k = 0; k < M; k++) nb[k] = k;
         std::stable_sort(nb.begin(), nb.end(), [&](int x, int y) { return dist2(pts[x], pts[seed]) < dist2(pts[y], pts[seed]); });
-        if (M < 5) continue;
-        P2 v[4];
-        for (int k = 0; k < 4; k++) v[k] = {pts[nb[1 + k]].r - pts[seed].r, pts[nb[1 + k]].c - pts[seed].c};
-        const P2 a = v[0];
-        P2 b{0, 0};
-        bool have_b = false;
-        for (int k = 1; k < 4; k++) {
-            const double dot = std::fabs(a.r * v[k].r + a.c * v[k].c);
-            if (dot < 0.5 * std::hypot(a.r, a.c) * std::hypot(v[k].r, v[k].c)) { b = v[k]; have_b = true; break; }
+        // The lattice's two axis directions at the seed: of its 8 nearest neighbours the one whose segment has the strongest edge
+        // contrast, and the strongest one not collinear with it (nearest-neighbour geometry alone picks a diagonal under strong
+        // perspective, where a foreshortened lattice's diagonal is shorter than its long axis -- oracle/detect_oracle.py order_grid)
+        const int nn = std::min(8, M - 1);
+        if (nn < 2) continue;
+        P2 v[8];
+        double con[8];
+        int ia = 0;
+        for (int k = 0; k < nn; k++) {
+            v[k] = {pts[nb[1 + k]].r - pts[seed].r, pts[nb[1 + k]].c - pts[seed].c};
+            con[k] = edge_contrast(pts[seed], v[k]);
+            if (con[k] > con[ia]) ia = k;              // (first maximum: the nearer neighbour on ties)
         }
-        if (!have_b) continue;
+        const P2 a = v[ia];
+        P2 b{0, 0};
+        double cb = -1.0;
+        for (int k = 0; k < nn; k++) {
+            const double dot = std::fabs(a.r * v[k].r + a.c * v[k].c);
+            if (k != ia && dot < 0.85 * std::hypot(a.r, a.c) * std::hypot(v[k].r, v[k].c) && con[k] > cb) { b = v[k]; cb = con[k]; }
+        }
+        if (cb < 0.0 || cb < 0.25 * con[ia]) continue;
         std::map<int, std::pair<int, int>> coord;
         std::map<int, std::pair<P2, P2>> basis;
         std::vector<int> queue{seed};
@@ -339,6 +362,32 @@ bool order_grid(const std::vector<P2> &pts, const std::vector<double> &resp, int
         const int e1 = imax - imin + 1, e2 = jmax - jmin + 1;
         std::vector<int> occ((size_t)e1 * e2, -1);
         for (int q : queue) occ[(size_t)(coord[q].first - imin) * e2 + (coord[q].second - jmin)] = q;
+        // every point of a candidate window is an X corner: an edge runs from it in all four lattice directions (towards the
+        // neighbour, or -- on the window's border -- the same step outwards: the board's outer ring of squares); a window shifted
+        // by a row onto response peaks of the outer squares' L corners has no edge beyond them
+        auto x_corners = [&](int o1, int o2, int m1, int m2) {
+            std::vector<double> cs;
+            auto at = [&](int i, int j) -> const P2 & { return pts[occ[(size_t)(o1 + i) * e2 + o2 + j]]; };
+            const int di[4] = {1, -1, 0, 0}, dj[4] = {0, 0, 1, -1};
+            for (int i = 0; i < m1; i++)
+                for (int j = 0; j < m2; j++)
+                    for (int k = 0; k < 4; k++) {
+                        const int i2 = i + di[k], j2 = j + dj[k];
+                        P2 vv;
+                        if (i2 >= 0 && i2 < m1 && j2 >= 0 && j2 < m2) {
+                            if (di[k] + dj[k] < 0) continue;       // (each inner segment once)
+                            vv = {at(i2, j2).r - at(i, j).r, at(i2, j2).c - at(i, j).c};
+                        } else {
+                            vv = {at(i, j).r - at(i - di[k], j - dj[k]).r, at(i, j).c - at(i - di[k], j - dj[k]).c};   // extrapolated outwards
+                        }
+                        cs.push_back(edge_contrast(at(i, j), vv));
+                    }
+            std::vector<double> srt(cs);
+            std::sort(srt.begin(), srt.end());
+            const size_t n = srt.size();
+            const double med = n % 2 ? srt[n / 2] : 0.5 * (srt[n / 2 - 1] + srt[n / 2]);     // numpy.median
+            return srt[0] >= 0.25 * med;
+        };
         for (int swap = 0; swap < 2 && grid.empty(); swap++) {
             const int m1 = swap ? n2 : n1, m2 = swap ? n1 : n2;
             if (e1 < m1 || e2 < m2) continue;
@@ -354,7 +403,7 @@ bool order_grid(const std::vector<P2> &pts, const std::vector<double> &resp, int
                             if (q < 0) { full = false; break; }
                             sc_ += resp[q];
                         }
-                    if (full && sc_ > score) { score = sc_; b1 = o1; b2 = o2; }
+                    if (full && x_corners(o1, o2, m1, m2) && sc_ > score) { score = sc_; b1 = o1; b2 = o2; }
                 }
             if (b1 < 0) continue;
             grid.assign((size_t)n1 * n2, -1);

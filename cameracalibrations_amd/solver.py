@@ -134,6 +134,12 @@ class Solver:
         F.check(F.lib().ccal_get_init(self._h, ip, rp if extrinsics else None))
         return intr, (rt if extrinsics else None)
 
+    def debug_homographies(self):
+        """(N, 2, 3, 3): per image the polished board -> pixel homography and the DLT's result before its polish (intrinsics stage)"""
+        H, hp = F.out64(self.N, 18)
+        F.check(F.lib().ccal_debug_get_homographies(self._h, hp))
+        return H.reshape(self.N, 2, 3, 3)
+
     def set_sweep_timing(self, enable=True):
         F.check(F.lib().ccal_set_sweep_timing(self._h, int(bool(enable))))
 

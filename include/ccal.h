@@ -37,6 +37,12 @@ extern "C" {
 /* status codes */
 #define CCAL_OK            0
 #define CCAL_W_MAX_ITER    1   /* stopped on max_iter, not on eps */
+#define CCAL_W_RANK_DEFICIENT 2 /* (bit, may come with CCAL_W_MAX_ITER as 3) the fit returned, but in its last sweep the damped 6 x 6
+                                 * block of at least one view could not be factored (a zero or non-finite diagonal: ccal_stats.n_bad
+                                 * counts the views); such a view's pose is left where it was.  Marquardt's damping keeps every system
+                                 * with a positive diagonal positive definite, and a parameter whose column is exactly zero gets a zero
+                                 * step -- the minimum-norm solution OpenCV's SVD returns for it -- so on finite, observable data the
+                                 * Cholesky / Gauss-Jordan steps here and OpenCV's DECOMP_SVD step solve the same nonsingular system */
 #define CCAL_E_ARG        -1   /* bad argument / unsupported flag (rational, thin-prism, tilted models) */
 #define CCAL_E_NONPLANAR  -2   /* template not planar with z == 0 and no intrinsic guess (OpenCV throws likewise) */
 #define CCAL_E_DEGENERATE -3   /* homography / pose initialisation failed */
@@ -288,6 +294,10 @@ int  ccal_debug_image_grams(ccal_ctx *ctx, const double intr[CCAL_NINTR], const 
  * out[0..67] = the column sums (the last column carries no value; the error column, 63, turns NaN / +inf when a
  * NaN / out-of-range value was added). */
 int  ccal_debug_acc_sum(ccal_ctx *ctx, const double *rows, int32_t n_rows, int32_t replicas, double out[68]);
+/* the per-image homographies the intrinsics stage (ccal_init_intrinsics) left on the device: H[N][18] row-major, the polished
+ * board -> pixel homography (9, H[8] = 1) followed by the normalised DLT's result before its polish (9).  CCAL_E_STATE when no
+ * intrinsics stage has run on the current corners.  (tools/fuzz_case.py: where an initial focal length comes from) */
+int  ccal_debug_get_homographies(ccal_ctx *ctx, double *H_host);
 /* the xGMI row exchange on its own, at any world size on one GPU: `world` (1..16) workgroups of ONE launch act as the ranks of a
  * node (rank r = workgroup r, its own inbox in this device's memory) and run `rounds` consecutive exchanges numbered the way a
  * series of solves numbers them (three trials per solve, then the next sequence number, starting at seq0 -- 0xFFFD.. crosses the

@@ -169,17 +169,58 @@ def order_grid(pts, resp, n1, n2, im):
         q = int(np.argmin(((pts - p) ** 2).sum(1)))
         return q, float(np.sqrt(((pts[q] - p) ** 2).sum()))
 
+    def edge_contrast(p, v):
+        """|gray difference| across the segment p -> p + v at its midpoint, a quarter of its length to either side: a lattice
+        AXIS neighbour's segment runs along the edge between a dark and a bright square (large), a diagonal neighbour's through
+        the middle of one square and a two-step neighbour's midpoint is itself a corner (both ~0)"""
+        ln = float(np.hypot(v[0], v[1]))
+        n = np.array([-v[1], v[0]]) / ln
+        mid = p + 0.5 * v
+
+        def px(q):
+            r = min(max(int(round(float(q[0]))), 0), im.shape[0] - 1)
+            c = min(max(int(round(float(q[1]))), 0), im.shape[1] - 1)
+            return float(im[r, c])
+        return abs(px(mid + 0.25 * ln * n) - px(mid - 0.25 * ln * n))
+
+    def x_corners(win):
+        """every point of a candidate window is an X corner: an edge runs from it in all four lattice directions (towards the
+        neighbour, or -- on the window's border -- the same step outwards: the board's outer ring of squares).  A window shifted by
+        a row onto response peaks of the outer squares' L corners has no edge beyond them."""
+        g = pts[win]
+        m1_, m2_ = win.shape
+        cs = []
+        for i in range(m1_):
+            for j in range(m2_):
+                for di, dj in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                    i2, j2 = i + di, j + dj
+                    if 0 <= i2 < m1_ and 0 <= j2 < m2_:
+                        if di + dj < 0:
+                            continue                      # (each inner segment once)
+                        v = g[i2, j2] - g[i, j]
+                    else:
+                        v = g[i, j] - g[i - di, j - dj]    # extrapolated outwards
+                    cs.append(edge_contrast(g[i, j], v))
+        cs = np.array(cs)
+        return bool(cs.min() >= 0.25 * np.median(cs))
+
     seeds = np.argsort(((pts - pts.mean(0)) ** 2).sum(1), kind="stable")[:5]
     best = None
     for seed in seeds:
-        nb = np.argsort(d2[seed], kind="stable")[1:5]
+        # the lattice's two axis directions at the seed: of its 8 nearest neighbours the one whose segment has the strongest edge
+        # contrast, and the strongest one not collinear with it.  (Nearest-neighbour geometry alone -- rounds 1-4: the nearest
+        # point and the first of the next three within 60 degrees of perpendicular -- picks a diagonal under strong perspective,
+        # where a foreshortened lattice's diagonal is shorter than its long axis: a sheared basis indexes the board as a
+        # parallelogram and no full n1 x n2 window exists; 13 of 100 boards at tilts up to 0.9 rad, all lost here.)
+        nb = np.argsort(d2[seed], kind="stable")[1:9]
         v = pts[nb] - pts[seed]
-        a, b = v[0], None
-        for q in v[1:]:
-            if abs(a @ q) < 0.5 * np.linalg.norm(a) * np.linalg.norm(q):
-                b = q
-                break
-        if b is None:
+        con = np.array([edge_contrast(pts[seed], q) for q in v])
+        ia = int(np.argmax(con))                          # (first maximum: the nearer neighbour on ties)
+        a, b, cb = v[ia], None, -1.0
+        for k, q in enumerate(v):
+            if k != ia and abs(a @ q) < 0.85 * np.linalg.norm(a) * np.linalg.norm(q) and con[k] > cb:
+                b, cb = q, con[k]
+        if b is None or cb < 0.25 * con[ia]:
             continue
         coord, basis, queue = {int(seed): (0, 0)}, {int(seed): (a, b)}, [int(seed)]
         while queue:
@@ -208,7 +249,7 @@ def order_grid(pts, resp, n1, n2, im):
             for o1 in range(ext[0] - m1 + 1):
                 for o2 in range(ext[1] - m2 + 1):
                     win = occ[o1:o1 + m1, o2:o2 + m2]
-                    if (win < 0).any():
+                    if (win < 0).any() or not x_corners(win):
                         continue
                     sc = resp[win].sum()
                     if sc > score:

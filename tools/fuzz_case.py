@@ -46,6 +46,13 @@ with Solver(0) as s:
     st, r = s.calibrate()
     tr = [t for t in s.trace() if t["accepted"] != 2]
     i0, rt0 = s.get_init()
+    s.init_intrinsics()
+    Hd = s.debug_homographies()
+for i in range(min(wl.n_images, 3)):
+    Ho_dlt = orc.find_homography(wl.obj[:, :2], wl.img[i], refine=False)
+    Ho = orc.find_homography(wl.obj[:, :2], wl.img[i], refine=True)
+    print(f"view {i}: homography |device - oracle| / |H|: DLT {np.abs(Hd[i, 1] - Ho_dlt).max() / np.abs(Ho_dlt).max():.2e}   "
+          f"polished {np.abs(Hd[i, 0] - Ho).max() / np.abs(Ho).max():.2e}   (polish moved it by {np.abs(Ho - Ho_dlt).max() / np.abs(Ho).max():.2e})")
 print(f"device: iters {r['iters']} rms {r['rms']!r}   oracle: iters {ro['iters']} rms {ro['rms']!r}")
 print("initial intrinsics |device - oracle|:", float(np.abs(i0 - ro["init_intr"]).max()))
 to = ro["trace"]

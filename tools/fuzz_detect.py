@@ -51,7 +51,7 @@ def render(n1, n2, rv, tv, blur_sigma, noise):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8), truth
 
 
-found, good, n_cases = 0, 0, 0
+found, good, n_cases, lost = 0, 0, 0, {}
 for case in range(args.cases):
     n1, n2 = int(rng.integers(4, 10)), int(rng.integers(4, 10))
     if n1 == n2:
@@ -67,7 +67,20 @@ for case in range(args.cases):
     n_cases += 1
     res = detect_corners(img, (n1, n2))
     if res is None:
-        print(f"case {case}: {n1}x{n2} rv={np.round(rv, 2)} z={z:.1f}: NOT FOUND")
+        # which stage lost the board: the numpy statement of the same detector (oracle/detect_oracle.py, equal to the device to
+        # 1e-13 px on boards both find), stage by stage
+        from oracle import detect_oracle as D
+        imf = np.asarray(img, dtype=np.float64)
+        pts, resp = D.peaks(D.chess_response(D.blur(imf)))
+        near = sum(1 for t in truth if len(pts) and np.linalg.norm(pts - t, axis=1).min() < 2.0)
+        if near < n1 * n2:
+            why = f"peak list: {near} of {n1 * n2} true corners have a response peak within 2 px ({len(pts)} peaks in all)"
+        else:
+            p2, r2 = D.merge_close(D.corner_subpix(imf, pts), resp)
+            why = ("lattice growth / ordering: every corner has its peak" if D.order_grid(p2, r2, n1, n2, imf) is None
+                   else "device only (the oracle finds this board)")
+        lost[why.split(":")[0]] = lost.get(why.split(":")[0], 0) + 1
+        print(f"case {case}: {n1}x{n2} rv={np.round(rv, 2)} z={z:.1f}: NOT FOUND -- {why}")
         continue
     found += 1
     det = res.transpose(1, 0, 2).reshape(-1, 2)          # first dimension fastest, like the template
@@ -78,4 +91,4 @@ for case in range(args.cases):
         good += 1
     else:
         print(f"case {case}: {n1}x{n2} rv={np.round(rv, 2)} z={z:.1f}: max corner error {err:.2f} px")
-print(f"{n_cases} boards rendered, {found} found, {good} with every corner within 1 px")
+print(f"{n_cases} boards rendered, {found} found, {good} with every corner within 1 px; lost by stage: {lost}")
