@@ -709,8 +709,8 @@ def roofline_block(N_rank, P, K, sweep_us, n_timed, b2b_us, events_ms_per_step, 
            "fp64_frac": tflops / FP64_PEAK_TFLOPS}
     # traffic: HBM-side bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/pmc.sh:
     # FETCH_SIZE and WRITE_SIZE in separate passes, both calibrated on a known byte count with this access width)
-    for shape, names in (((1000, 54), ("r04_pmc_traffic_summary.json", "r03_pmc_traffic_summary.json", "r02_pmc_traffic_summary.json")),
-                         ((10000, 150), ("r04_c5_pmc_traffic_summary.json", "r03_c5_pmc_traffic_summary.json"))):
+    for shape, names in (((1000, 54), ("r05_pmc_traffic_summary.json", "r04_pmc_traffic_summary.json", "r03_pmc_traffic_summary.json")),
+                         ((10000, 150), ("r05_c5_pmc_traffic_summary.json", "r04_c5_pmc_traffic_summary.json", "r03_c5_pmc_traffic_summary.json"))):
         for name in names:
             pmc = committed_profile(name)
             if pmc and (N_rank, P) == shape and "ccal::k_lm_trial" in pmc and out["traffic"] is None:

@@ -153,6 +153,15 @@ static void drop_pending_focal(ccal_ctx *c) {
     }
 }
 
+// d_intr0 is only complete once the pose stage that carries the pending focal solve has been enqueued: entry points that read the
+// initial intrinsics refuse a context whose pipeline was abandoned between its two initialisation stages
+static bool intr_incomplete(const ccal_ctx *c) { return c->focal_pending; }
+#define REFUSE_PENDING_FOCAL(c, who)                                                                                              \
+    do {                                                                                                                          \
+        if (intr_incomplete(c))                                                                                                   \
+            return fail(CCAL_E_STATE, who ": the intrinsics stage of an abandoned pipeline is incomplete (call ccal_init_intrinsics again)"); \
+    } while (0)
+
 static void free_problem_buffers(ccal_ctx *c) {
     (void)hipFree(c->d_obj); (void)hipFree(c->d_img_own); (void)hipFree(c->d_ext0); (void)hipFree(c->d_blk);
     (void)hipFree(c->d_H); (void)hipFree(c->d_foc_partials); (void)hipFree(c->d_gram);
@@ -902,6 +911,7 @@ static int lm_prepare(ccal_ctx *c) {
     if (!c) return fail(CCAL_E_ARG, "ccal_lm_run: ctx == NULL");
     if (!c->have_problem || !c->have_img || !c->have_intr || !c->have_ext)
         return fail(CCAL_E_STATE, "ccal_lm_run: initial intrinsics / extrinsics / image points not set");
+    REFUSE_PENDING_FOCAL(c, "ccal_lm_run");
     HIPCHK(hipSetDevice(c->device));
     if (c->wpi_sharded != sharded(c)) resolve_wpi(c);   // a transport was attached or dropped since the problem was set
     c->run_t0 = now_s();
@@ -1131,6 +1141,7 @@ int ccal_get_init(ccal_ctx *c, double intr[CCAL_NINTR], double *rt_host) {
     HIPCHK(hipSetDevice(c->device));
     if (intr) {
         if (!c->have_intr) return fail(CCAL_E_STATE, "ccal_get_init: no initial intrinsics");
+        REFUSE_PENDING_FOCAL(c, "ccal_get_init");
         memcpy(intr, c->intr0, sizeof c->intr0);
     }
     if (rt_host) {
@@ -1696,6 +1707,7 @@ int ccal_time_sweep(ccal_ctx *c, int32_t reps, double *avg_us) {
     if (!c || !avg_us || reps < 1) return fail(CCAL_E_ARG, "ccal_time_sweep: bad argument");
     if (!c->have_problem || !c->have_img || !c->have_intr || !c->have_ext)
         return fail(CCAL_E_STATE, "ccal_time_sweep: needs image points and a parameter point");
+    REFUSE_PENDING_FOCAL(c, "ccal_time_sweep");
     HIPCHK(hipSetDevice(c->device));
     // a first-trial launch (state boot + full sweep) at the last result if there is one, else at the
     // initial values; back-to-back launches, so the mean includes one kernel boundary

@@ -3,7 +3,7 @@
 # here): rocprofv3 kernel stats of the C3 bench as the driver runs it, of C5 whole and of its per-GPU share at 8 GPUs, of the
 # map / metric entry points; PMC traffic (C3 and C5) and utilisation passes (their own runs: --pmc with --kernel-trace only);
 # wave stamps.          tools/profiles.sh <round, e.g. r03>
-R=${1:-r04}; O=gpurun_out/${R}_prof; mkdir -p $O gpurun_out
+R=${1:-r05}; O=gpurun_out/${R}_prof; mkdir -p $O gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c3 -o prof -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $O/c3.log 2>&1; echo "c3 stats exit $?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -o prof -- python3 bench.py --workload C5 --steps 20 --warmup 3 --no-cpu-baseline --timed-only > $O/c5.log 2>&1; echo "c5 stats exit $?"
