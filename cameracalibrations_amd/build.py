@@ -19,6 +19,11 @@ LIB = os.path.join(HERE, "libccal_hip.so")
 # max-ilp: the hot kernels run one wave per SIMD, so the scheduler should hide FP64 latency inside the wave
 # rather than save registers for occupancy (measured: 10.8 -> 10.45 us per k_lm_trial launch)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+# Per-file flags.  ccal_init.hip: contraction decided per source expression (-ffp-contract=on) instead of by the optimiser across
+# statements (the HIP default, fast): the pose kernel exists in a pipeline and a stage-by-stage instantiation that must give the same
+# bits (tests: pipeline == stages), and under `fast` whether a product is fused into a later sum depends on what the optimiser sees
+# around it in each instantiation.
+EXTRA_FLAGS = {"ccal_init.hip": ["-ffp-contract=on"]}
 
 
 def _stale(target, deps):
@@ -37,7 +42,7 @@ def build(force=False, verbose=False):
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc, *FLAGS, "-c", s, "-o", o]
+            cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

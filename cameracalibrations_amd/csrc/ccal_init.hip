@@ -180,6 +180,53 @@ __device__ double homog_error(const Pts &pts, int P, int lane, const double h[8]
     return wave_sum(s);
 }
 
+// ---- SPD solves with ONE MATRIX ROW PER LANE (round 5) ----------------------------------------------------------------------
+// The step of the per-view polishes solves a damped 6 x 6 (pose) system.  As wave-uniform arithmetic (every lane the same
+// Cholesky factor + two substitutions) that is a 1.0 k-cycle dependent chain per iteration of the image the launch waits for; with
+// row i of [A | b] in lane i of every row of 16 lanes and the pivot row broadcast by DPP (the scaled Gauss-Jordan elimination of
+// the LM advance, ccal_math.hpp gj_row_step: raw v_rcp_f64 estimate, no refined reciprocal on the chain) it is N pivots of four
+// dependent operations.  The rows come straight out of the lane sums' LDS totals (wave_sums_lds_reduce): 7 reads per lane
+// instead of 28 broadcast reads.
+#ifndef CCAL_POSE_GJ
+#define CCAL_POSE_GJ 1
+#endif
+__device__ __forceinline__ double rcp_refined(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-d, y, 1.0);
+    return fma(y, e, y);
+}
+template <int N, int J>
+__device__ __forceinline__ void gj_rows_steps(double (&a)[N], double &b, double &diag, bool &ok, int la) {
+    const double d = row_bcast16<J>(a[J]);          // pivot
+    ok = ok && (d > 0.0) && (d < 1.0e300);
+    double prow[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) prow[k] = k > J ? row_bcast16<J>(a[k]) : 0.0;
+    const double pb = row_bcast16<J>(b);
+    gj_row_step<N>(J, la == J, d, __builtin_amdgcn_rcp(d), prow, pb, a, b, diag);
+    if constexpr (J + 1 < N) gj_rows_steps<N, J + 1>(a, b, diag, ok, la);
+}
+template <int N, int K>
+__device__ __forceinline__ void bcast_rows(double xv, double (&x)[N]) {
+    x[K] = row_bcast16<K>(xv);
+    if constexpr (K + 1 < N) bcast_rows<N, K + 1>(xv, x);
+}
+// a = row `la` of the SPD matrix, b = its right-hand side entry (la = min(lane & 15, N - 1): every row of 16 lanes holds the whole
+// system, lanes beyond N - 1 mirror the last row) -> x[N] in every lane; false: a pivot was not positive (x unusable)
+template <int N>
+__device__ __forceinline__ bool gj_solve_rows(double (&a)[N], double b, int la, double (&x)[N]) {
+    bool ok = true;
+    double diag = 1.0;
+    gj_rows_steps<N, 0>(a, b, diag, ok, la);
+    const double rd = rcp_refined(diag);
+    double xv = b * rd;
+    xv = fma(fma(-diag, xv, b), rd, xv);            // x_la = b / a_la,la, one correction step on the quotient
+    bcast_rows<N, 0>(xv, x);
+    return (__ballot(ok) & 1ull) != 0;              // (lane 0's view: every lane made the same pivot tests)
+}
+
 // A (8x8 packed lower) = J^T J, v = J^T r, S = r^T r at h.  The u-row of a correspondence touches only parameters
 // {0,1,2,6,7} and the v-row only {3,4,5,6,7}, and both carry the same first three entries (Mx w, My w, w): of the 45
 // entries 30 are distinct non-zero sums -- formed per lane, accumulated over the passes and summed over the lanes once
@@ -241,6 +288,9 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, d
     // next iteration's, and LMSolver's separate error-only evaluation is saved.  After a rejected step -- near convergence
     // they come in runs: the polish on pixel coordinates spends its last iterations there -- the trial goes back to the
     // cheap error-only pass, and the normal equations follow only on acceptance.  Same decisions, same points.
+    // (The lane-parallel solve of the pose step -- gj_solve_rows -- was tried here too, round 5, with the rows of the 8 x 8 system
+    //  read out of the lane sums' LDS totals through an index map: slower -- C1's pose stage 30.5 -> 47.8 us, C5's intrinsics stage
+    //  183 -> 258 us: both kernels sit at their register limit and the extra row state spills.)
     double A[36], v[8], D[8], S, rmax;
     homog_normal_eq(pts, P, lane, x, scratch, A, v, S, rmax);
 #pragma unroll
@@ -730,9 +780,12 @@ __device__ double view_error(const float *obj, const float2 *img, int P, int lan
 // JtJ (6x6 packed), Jt e and ||e||^2 of one view: 28 sums over the corners, formed per lane, accumulated over the
 // passes and summed over the lanes once (wave_sums_lds)
 constexpr int VSUMS = 28;
+// ROWS: JtJ[0..5] = row min(lane & 15, 5) of JtJ and JtErr[0] = that row's entry of Jt e (gj_solve_rows' layout) instead of the
+// packed matrix and the whole vector in every lane
+template <bool ROWS = false>
 __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int lane, const double rt[6],
                                  const double R[9], const double K[9], const double in[NINTR], double *scratch,
-                                 double JtJ[21], double JtErr[6], const FirstPoint &fp) {
+                                 double *JtJ, double *JtErr, const FirstPoint &fp) {
     double acc[VSUMS];
 #pragma unroll
     for (int k = 0; k < VSUMS; k++) acc[k] = 0.0;
@@ -757,14 +810,29 @@ __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int
         acc[27] += mu[COL_E] * mu[COL_E] + mv[COL_E] * mv[COL_E];
     }
     JSUB(2);
-    double t[VSUMS];
-    wave_sums_lds<VSUMS>(acc, scratch, lane, t);
+    if constexpr (ROWS) {
+        const double *res = wave_sums_lds_reduce<VSUMS>(acc, scratch, lane);
+        const int la = min(lane & 15, 5);
 #pragma unroll
-    for (int k = 0; k < 21; k++) JtJ[k] = t[k];
+        for (int k = 0; k < 6; k++) {
+            const int hi = max(la, k), lo = min(la, k);
+            JtJ[k] = res[hi * (hi + 1) / 2 + lo];
+        }
+        JtErr[0] = res[21 + la];
+        const double e2 = res[27];
+        wave_lds_sync();                              // the scratch may be overwritten by the next call
+        JSUB(3);
+        return e2;
+    } else {
+        double t[VSUMS];
+        wave_sums_lds<VSUMS>(acc, scratch, lane, t);
 #pragma unroll
-    for (int a = 0; a < 6; a++) JtErr[a] = t[21 + a];
-    JSUB(3);
-    return t[27];
+        for (int k = 0; k < 21; k++) JtJ[k] = t[k];
+#pragma unroll
+        for (int a = 0; a < 6; a++) JtErr[a] = t[21 + a];
+        JSUB(3);
+        return t[27];
+    }
 }
 
 // SPEC: trial points of the two polishes by their normal-equations passes (shortest chain per image: up to one image per
@@ -943,11 +1011,19 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
     }
 
     // ---- [OCV-K CvLevMarq(6, 2P, (COUNT+EPS, 20, FLT_EPSILON))::update] ----
-    double prev[6], JtJ[21], JtErr[6];
+    // (CCAL_POSE_GJ: JtJ / JtErr hold ONE ROW per lane -- JtJ[0..5], JtErr[0] -- for the lane-parallel solve of the step)
+    // (latency form only: in the throughput form -- more images than SIMDs -- the DPP chain is no shorter than the wave-uniform
+    //  Cholesky's issue time and C5's pose stage measured 320 -> 330 us with it; C3: 69.8 -> 65.5 us, tools/init_timing.py)
+    constexpr bool GJ = CCAL_POSE_GJ != 0 && SPEC;
+    constexpr int NJ = GJ ? 6 : 21, NE = GJ ? 1 : 6;
+    const int la6 = min(lane & 15, 5);
+    double prev[6], JtJ[NJ], JtErr[NE];
 #pragma unroll
-    for (int k = 0; k < 6; k++) { prev[k] = rt[k]; JtErr[k] = 0.0; }
+    for (int k = 0; k < 6; k++) prev[k] = rt[k];
 #pragma unroll
-    for (int k = 0; k < 21; k++) JtJ[k] = 0.0;
+    for (int k = 0; k < NE; k++) JtErr[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NJ; k++) JtJ[k] = 0.0;
     ISTAMP(2);
     // lambda = 10^lambdaLg10 as OpenCV forms it, exp(lambdaLg10 * log(10)): tabulated once (lane l holds entry l)
     // instead of one double-precision exp per step
@@ -979,7 +1055,7 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
     // follows on acceptance: a view whose third or fourth step lands on the optimum to rounding rejects the next one six to
     // nine times in a row (lambda has to climb from 1e-6 past 1 before the step shrinks), and a launch of up to one image per
     // SIMD is as long as its slowest image.
-    double JtJ_c[21], JtErr_c[6];
+    double JtJ_c[NJ], JtErr_c[NE];
     bool have_cand = false, after_reject = false;
     for (int guard = 0; ok && guard < 20 * 24; guard++) {
         bool do_step = false;
@@ -1008,9 +1084,11 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
                 if (SPEC && have_cand) {
                     // the accepted point's normal equations are already here: CALC_J's bookkeeping and the step at once
 #pragma unroll
-                    for (int k = 0; k < 21; k++) JtJ[k] = JtJ_c[k];
+                    for (int k = 0; k < NJ; k++) JtJ[k] = JtJ_c[k];
 #pragma unroll
-                    for (int k = 0; k < 6; k++) { JtErr[k] = JtErr_c[k]; prev[k] = rt[k]; }
+                    for (int k = 0; k < NE; k++) JtErr[k] = JtErr_c[k];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) prev[k] = rt[k];
                     have_cand = false;
                     do_step = true;
                     state = 3;
@@ -1024,17 +1102,27 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
 #endif
         if (do_step) {
             // CvLevMarq::step: diag *= 1 + lambda; solve; param = prev - delta
-            double A[21], d[6];
+            const double lam = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pow10_l), lambdaLg10 + 16),
+                                                __builtin_amdgcn_readlane(__double2loint(pow10_l), lambdaLg10 + 16));
+            double d[6];
+            bool pd;
+            if constexpr (GJ) {
+                double A6[6];
 #pragma unroll
-            for (int k = 0; k < 21; k++) A[k] = JtJ[k];
+                for (int k = 0; k < 6; k++) A6[k] = (la6 == k) ? JtJ[k] * (1.0 + lam) : JtJ[k];
+                pd = gj_solve_rows<6>(A6, JtErr[0], la6, d);
+            } else {
+                double A[21];
 #pragma unroll
-            for (int k = 0; k < 6; k++) d[k] = JtErr[k];
-            damp_diag<6>(A, __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(pow10_l), lambdaLg10 + 16),
-                                             __builtin_amdgcn_readlane(__double2loint(pow10_l), lambdaLg10 + 16)));
-            double ip6[6];
-            const bool pd = chol_packed<6>(A, ip6);
-            fwd_subst<6>(A, ip6, d);
-            bwd_subst<6>(A, ip6, d);
+                for (int k = 0; k < 21; k++) A[k] = JtJ[k];
+#pragma unroll
+                for (int k = 0; k < 6; k++) d[k] = JtErr[k];
+                damp_diag<6>(A, lam);
+                double ip6[6];
+                pd = chol_packed<6>(A, ip6);
+                fwd_subst<6>(A, ip6, d);
+                bwd_subst<6>(A, ip6, d);
+            }
 #pragma unroll
             for (int k = 0; k < 6; k++) rt[k] = prev[k] - (pd ? d[k] : 0.0);
             rodrigues_RK(rt, R, K);
@@ -1043,8 +1131,8 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
         const unsigned long long ts1 = memtime_now();
         if (do_step) t_step += ts1 - ts0;
 #endif
-        if (state == 2) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_sums, JtJ, JtErr, fp)); n_j++; }
-        else if (SPEC && !after_reject) { errNorm = sqrt(view_normal_eq(obj, img_i, P, lane, rt, R, K, in, s_sums, JtJ_c, JtErr_c, fp)); have_cand = true; n_e++; }
+        if (state == 2) { errNorm = sqrt(view_normal_eq<GJ>(obj, img_i, P, lane, rt, R, K, in, s_sums, JtJ, JtErr, fp)); n_j++; }
+        else if (SPEC && !after_reject) { errNorm = sqrt(view_normal_eq<GJ>(obj, img_i, P, lane, rt, R, K, in, s_sums, JtJ_c, JtErr_c, fp)); have_cand = true; n_e++; }
         else { errNorm = sqrt(view_error(obj, img_i, P, lane, rt, R, in, fp)); n_e++; }
 #ifdef CCAL_STAMPS
         const unsigned long long ts2 = memtime_now();

@@ -149,8 +149,11 @@ __device__ __forceinline__ void tile_gram(const double *tile, int lane, int npts
 constexpr int SUMS_LD = 66;
 constexpr int sums_scratch_doubles(int nv) { return SUMS_LD * nv + 64; }
 
+// The reduce alone: -> the NV totals, left in LDS (readable by every lane; the caller calls wave_lds_sync() when it has read what
+// it needs, before the scratch is used again) -- for callers that want a per-lane selection of the totals (one matrix row per
+// lane: ccal_init.hip's lane-parallel solves) instead of all of them in every lane.
 template <int NV>
-__device__ __forceinline__ void wave_sums_lds(const double (&v)[NV], double *scratch, int lane, double (&out)[NV]) {
+__device__ __forceinline__ const double *wave_sums_lds_reduce(const double (&v)[NV], double *scratch, int lane) {
     static_assert(NV >= 1 && NV <= 64, "one row per lane at most");
 #pragma unroll
     for (int j = 0; j < NV; j++) scratch[j * SUMS_LD + lane] = v[j];
@@ -179,9 +182,6 @@ __device__ __forceinline__ void wave_sums_lds(const double (&v)[NV], double *scr
             part = __hiloint2double(sh[0], sl[0]) + __hiloint2double(sh[1], sl[1]);
         }
         if (lane < 32) res[lane] = part;
-        wave_lds_sync();
-#pragma unroll
-        for (int j2 = 0; j2 < NV; j2++) out[j2] = res[j2];
     } else {
         double part = 0.0;
         if (lane < NV) {
@@ -196,12 +196,19 @@ __device__ __forceinline__ void wave_sums_lds(const double (&v)[NV], double *scr
             part = a0 + a1;
         }
         res[lane] = part;
-        wave_lds_sync();
-#pragma unroll
-        for (int j2 = 0; j2 < NV; j2++) out[j2] = res[j2];
     }
+    wave_lds_sync();
+    return res;
+}
+
+template <int NV>
+__device__ __forceinline__ void wave_sums_lds(const double (&v)[NV], double *scratch, int lane, double (&out)[NV]) {
+    const double *res = wave_sums_lds_reduce<NV>(v, scratch, lane);
+#pragma unroll
+    for (int j2 = 0; j2 < NV; j2++) out[j2] = res[j2];
     wave_lds_sync();                                          // the scratch may be overwritten by the next call
 }
+
 
 // v_mfma_f64_16x16x4_f64 C/D layout: column = lane & 15, row = (lane >> 4) + 4 * reg.
 __device__ __forceinline__ void gram_to_lds(double *Gs, int lane, const d4 &acc0, const d4 &acc1) {

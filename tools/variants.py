@@ -10,13 +10,17 @@ from cameracalibrations_amd import build as B  # noqa: E402
 
 def build_variant(name, defines):
     out_dir = os.path.join(ROOT, "build_variants")
-    os.makedirs(out_dir, exist_ok=True)
+    obj_dir = os.path.join(out_dir, "obj_" + name)
+    os.makedirs(obj_dir, exist_ok=True)
     out = os.path.join(out_dir, name + ".so")
-    srcs = [os.path.join(B.CSRC, s) for s in B.SOURCES]
     # an entry starting with '@' is passed to the compiler as it is (e.g. @-mllvm,@-amdgpu-kernarg-preload-count=16)
     extra = [d[1:] if d.startswith("@") else "-D" + d for d in defines]
-    cmd = ["/opt/rocm/bin/hipcc", *B.FLAGS, "-shared", *extra, "-o", out, *srcs, "-ldl"]
-    subprocess.check_call(cmd)
+    objs = []
+    for src in B.SOURCES:                         # file by file, with the product build's per-file flags (build.EXTRA_FLAGS)
+        o = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        subprocess.check_call(["/opt/rocm/bin/hipcc", *B.FLAGS, *B.EXTRA_FLAGS.get(src, []), *extra, "-c", os.path.join(B.CSRC, src), "-o", o])
+        objs.append(o)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-ldl"])
     return out
 
 
