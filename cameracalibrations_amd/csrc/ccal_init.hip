@@ -190,6 +190,9 @@ __device__ double homog_error(const Pts &pts, int P, int lane, const double h[8]
 #ifndef CCAL_POSE_GJ
 #define CCAL_POSE_GJ 1
 #endif
+#ifndef CCAL_HOMOG_BLOCKS
+#define CCAL_HOMOG_BLOCKS 1
+#endif
 __device__ __forceinline__ double rcp_refined(double d) {
     double y = __builtin_amdgcn_rcp(d);
     double e = fma(-d, y, 1.0);
@@ -278,6 +281,52 @@ __device__ void homog_normal_eq(const Pts &pts, int P, int lane, const double h[
     S = t[29];
 }
 
+// d = (A + lambda diag(D))^-1 v for the homography polish's 8 x 8 normal equations, by their block structure (round 5):
+//     A = [T 0 U^T; 0 T V^T; U V W]   T 3 x 3 (the SAME block twice: both image coordinates see the same template moments, and
+//                                     D = the first iteration's diagonal damps both alike), U, V 2 x 3, W 2 x 2
+// One 3 x 3 Cholesky factor serves both blocks, the 2 x 2 Schur complement S = W - U T^-1 U^T - V T^-1 V^T closes the system:
+// five pivots on the dependent chain instead of the eight of a dense 8 x 8 factor, half the arithmetic.  false: not positive
+// definite (the dense factor's test, on the same pivots up to elimination order).
+__device__ __forceinline__ bool homog_solve_blocks(const double A[36], const double v[8], double lambda, const double D[8], double d[8]) {
+    double T[6], it[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b <= a; b++) T[tri(a, b)] = A[tri(a, b)] + (a == b ? lambda * D[a] : 0.0);
+    bool ok = chol_packed<3>(T, it);
+    // Y = L^-1 [U^T | V^T | v_p | v_q]: columns u0 u1 (rows 6, 7 of A, columns 0..2), w0 w1 (columns 3..5), v_p, v_q
+    double y[6][3];
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        y[0][b] = A[tri(6, b)]; y[1][b] = A[tri(7, b)]; y[2][b] = A[tri(6, 3 + b)]; y[3][b] = A[tri(7, 3 + b)];
+        y[4][b] = v[b]; y[5][b] = v[3 + b];
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++) fwd_subst<3>(T, it, y[c]);
+    auto dot3 = [](const double (&p)[3], const double (&q)[3]) { return p[0] * q[0] + p[1] * q[1] + p[2] * q[2]; };
+    double S[3], is[2], r[2];
+    S[0] = A[tri(6, 6)] + lambda * D[6] - dot3(y[0], y[0]) - dot3(y[2], y[2]);
+    S[1] = A[tri(7, 6)] - dot3(y[1], y[0]) - dot3(y[3], y[2]);
+    S[2] = A[tri(7, 7)] + lambda * D[7] - dot3(y[1], y[1]) - dot3(y[3], y[3]);
+    r[0] = v[6] - dot3(y[0], y[4]) - dot3(y[2], y[5]);
+    r[1] = v[7] - dot3(y[1], y[4]) - dot3(y[3], y[5]);
+    ok = chol_packed<2>(S, is) && ok;
+    fwd_subst<2>(S, is, r);
+    bwd_subst<2>(S, is, r);
+    double p[3], q[3];
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        p[b] = y[4][b] - y[0][b] * r[0] - y[1][b] * r[1];
+        q[b] = y[5][b] - y[2][b] * r[0] - y[3][b] * r[1];
+    }
+    bwd_subst<3>(T, it, p);
+    bwd_subst<3>(T, it, q);
+#pragma unroll
+    for (int b = 0; b < 3; b++) { d[b] = p[b]; d[3 + b] = q[b]; }
+    d[6] = r[0]; d[7] = r[1];
+    return ok;
+}
+
 // [OCV-K LMSolverImpl::run] with maxIters = 10, eps = FLT_EPSILON on the 8 free entries
 // SPEC = false: every trial by the error-only pass (LMSolver's own sequence): 44 fewer live doubles, which keeps
 // k_init_homography at two waves per SIMD where that matters (more images than SIMDs).
@@ -301,7 +350,13 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, d
     HSTAMP(6);
     for (int iter = 0;;) {
         HSTAMP(7);
-        double Ap[36], d[8], xd[8];
+        double d[8], xd[8];
+        // (latency form only: the throughput form runs at its register limit, and C5's intrinsics stage measured 181 -> 235 us with
+        //  the block solve's extra live values; C3: intrinsics stage 33.2 -> 31.8 us, full fit -1.8 us, tools/init_timing.py)
+        if constexpr (CCAL_HOMOG_BLOCKS != 0 && SPEC) {
+            if (!homog_solve_blocks(A, v, lambda, D, d)) break;   // degenerate normal equations: keep the current H
+        } else {
+        double Ap[36];
 #pragma unroll
         for (int k = 0; k < 36; k++) Ap[k] = A[k];
 #pragma unroll
@@ -310,6 +365,7 @@ __device__ void homog_refine(const Pts &pts, int P, int lane, double *scratch, d
         if (!chol_packed<8>(Ap, ipv)) break;            // degenerate normal equations: keep the current H
         fwd_subst<8>(Ap, ipv, d);
         bwd_subst<8>(Ap, ipv, d);
+        }
 #pragma unroll
         for (int a = 0; a < 8; a++) xd[a] = x[a] - d[a];
         HSTAMP(8);
