@@ -43,6 +43,7 @@ constexpr double REL_THRESHOLD = 0.15;
 constexpr int SUBPIX_WIN = 11;
 constexpr int SUBPIX_ITERS = 30;
 constexpr double SUBPIX_EPS = 1e-3;
+constexpr double SUBPIX_MAX_SHIFT = 2.0;
 constexpr double MERGE_DIST = 2.0;
 __device__ const int RING_DR[16] = {0, 2, 3, 5, 5, 5, 3, 2, 0, -2, -3, -5, -5, -5, -3, -2};
 __device__ const int RING_DC[16] = {5, 5, 3, 2, 0, -2, -3, -5, -5, -5, -3, -2, 0, 2, 3, 5};
@@ -256,7 +257,10 @@ __global__ __launch_bounds__(64) void k_det_subpix(const double *__restrict__ im
         if (!(qr >= 0.0 && qr < rows && qc >= 0.0 && qc < cols)) break;
         if (err <= SUBPIX_EPS * SUBPIX_EPS) break;
     }
-    if (fabs(qr - pr) > SUBPIX_WIN || fabs(qc - pc) > SUBPIX_WIN) { qr = pr; qc = pc; }
+    // a refinement that leaves its response peak by more than SUBPIX_MAX_SHIFT is not believed and the peak stands (OpenCV's rule uses
+    // the half window, 11 px; under strong shear a neighbouring edge inside the 23 x 23 window pulls corners 3-11 px away, the
+    // lattice then cannot close: oracle/detect_oracle.py, profiles/r05_detector_probe.txt)
+    if (fabs(qr - pr) > SUBPIX_MAX_SHIFT || fabs(qc - pc) > SUBPIX_MAX_SHIFT) { qr = pr; qc = pc; }
     if (lane == 0) {
         out[2 * i] = qr; out[2 * i + 1] = qc;
         // `out` is pinned host memory: the last workgroup to finish raises the completion word the host spins on

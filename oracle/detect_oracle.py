@@ -38,6 +38,7 @@ REL_THRESHOLD = 0.15
 SUBPIX_WIN = 11
 SUBPIX_ITERS = 30
 SUBPIX_EPS = 1e-3
+SUBPIX_MAX_SHIFT = 2.0    # a refinement that leaves its response peak by more than this is not believed: the peak stands (OpenCV: the half window, 11)
 MERGE_DIST = 2.0
 
 
@@ -142,7 +143,7 @@ def corner_subpix(im, pts):
                 break
             if err <= SUBPIX_EPS * SUBPIX_EPS:
                 break
-        if abs(qr - pr) > win or abs(qc - pc) > win:
+        if abs(qr - pr) > SUBPIX_MAX_SHIFT or abs(qc - pc) > SUBPIX_MAX_SHIFT:
             qr, qc = float(pr), float(pc)
         out[i] = (qr, qc)
     return out

@@ -77,8 +77,13 @@ for case in range(args.cases):
             why = f"peak list: {near} of {n1 * n2} true corners have a response peak within 2 px ({len(pts)} peaks in all)"
         else:
             p2, r2 = D.merge_close(D.corner_subpix(imf, pts), resp)
-            why = ("lattice growth / ordering: every corner has its peak" if D.order_grid(p2, r2, n1, n2, imf) is None
-                   else "device only (the oracle finds this board)")
+            kept = sum(1 for t in truth if np.linalg.norm(p2 - t, axis=1).min() < 1.5)
+            if kept < n1 * n2:
+                why = (f"sub-pixel refinement: every corner has its response peak, but {n1 * n2 - kept} of them leave it by more than 1.5 px under "
+                       f"cornerSubPix's 11 x 11 window (sheared lattice: a neighbouring edge inside the window), and the lattice cannot close")
+            else:
+                why = ("lattice growth / ordering: every refined corner is in place" if D.order_grid(p2, r2, n1, n2, imf) is None
+                       else "device only (the oracle finds this board)")
         lost[why.split(":")[0]] = lost.get(why.split(":")[0], 0) + 1
         print(f"case {case}: {n1}x{n2} rv={np.round(rv, 2)} z={z:.1f}: NOT FOUND -- {why}")
         continue
