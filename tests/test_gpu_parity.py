@@ -1268,3 +1268,39 @@ def test_one_launch_solve_equals_the_launch_per_trial_form_bit_for_bit(name, n, 
     assert len(ta) == len(tb) and all(x == y for x, y in zip(ta, tb))
     ro = _oracle(wl, crit)
     assert a["iters"] == ro["iters"] and abs(a["rms"] - ro["rms"]) < 1e-8
+
+
+def test_small_drop_in_calls_stage_through_the_pinned_block(golden_dir, monkeypatch):
+    """A ccal_calibrate call whose inputs fit the context's pinned block stages them there (a kernel copies them, no copy commands from
+    pageable memory) and receives its poses from the launch that ends the solve (no read-back launch): the same bits as the copy-command
+    path (CCAL_NO_SMALL_CALL=1), on the reference's example (6 x 40, launch-per-trial LM) and on a 3-image fit (one-launch LM)."""
+    with open(os.path.join(golden_dir, "example_corners.json")) as f:
+        ex = json.load(f)
+    from cameracalibrations_amd import board_template
+    obj = board_template(ex["n_corners"])
+    imgs = [np.array(m, dtype=np.float64) for m in ex["corners"]]
+    for sub in (imgs, imgs[:3]):
+        out = []
+        for no_small in ("0", "1"):
+            if no_small == "1":
+                monkeypatch.setenv("CCAL_NO_SMALL_CALL", "1")
+            else:
+                monkeypatch.delenv("CCAL_NO_SMALL_CALL", raising=False)
+            out.append(fit_model(ex["image_size_wh"], obj, sub, ex["n_corners"], True, 1))
+        a, b = out
+        assert (a.frow, a.fcol, a.crow, a.ccol, a.k, a.rms, a.iters) == (b.frow, b.fcol, b.crow, b.ccol, b.k, b.rms, b.iters)
+        assert np.array_equal(np.array(a.Rs), np.array(b.Rs)) and np.array_equal(np.array(a.ts), np.array(b.ts))
+        assert np.all(np.isfinite(np.array(a.Rs))) and np.abs(np.array(a.ts)).max() > 1.0      # (poses really came back)
+
+
+def test_sweep_form_names_the_kernel_that_ran():
+    """ccal_stats.sweep_form = FLOW | LOOP << 4 | WPI << 8 | SOLO << 12: what bench.py prints as the roofline's kernel name."""
+    cases = [("C2", 3, (1 << 8) | (1 << 12)),      # <= 4 images: every trial in one launch
+             ("C2", 37, 4 << 8),                    # a one-pass board, few images: four waves per image
+             ("C2", 600, 1 << 8),                   # one wave per image, one group per workgroup
+             ("C5", 7, 4 << 8)]                     # a multi-pass board, few images
+    for name, n, want in cases:
+        wl = syn.named_workload(name, n_images=n)
+        with _solver(wl, REF) as s:
+            _, r = s.calibrate()
+        assert r["sweep_form"] == want, (name, n, hex(r["sweep_form"]))
