@@ -857,13 +857,15 @@ __device__ double view_normal_eq(const float *obj, const float2 *img, int P, int
         JSUB(0);
         point_rows_K(M, (double)uv.x, (double)uv.y, R, K, rt + 3, in, 0.0, mu, mv, valid ? 1.0 : 0.0);   // padding lanes: zero rows
         JSUB(1);
+        // (two fused multiply-adds per sum: written out, since contraction follows the source expression in this file and
+        //  `acc += a b + c d` would be a product, a fused multiply-add and an addition)
 #pragma unroll
         for (int a = 0; a < 6; a++) {
 #pragma unroll
-            for (int b = 0; b <= a; b++) acc[tri(a, b)] += mu[a] * mu[b] + mv[a] * mv[b];
-            acc[21 + a] += mu[a] * mu[COL_E] + mv[a] * mv[COL_E];
+            for (int b = 0; b <= a; b++) acc[tri(a, b)] = fma(mv[a], mv[b], fma(mu[a], mu[b], acc[tri(a, b)]));
+            acc[21 + a] = fma(mv[a], mv[COL_E], fma(mu[a], mu[COL_E], acc[21 + a]));
         }
-        acc[27] += mu[COL_E] * mu[COL_E] + mv[COL_E] * mv[COL_E];
+        acc[27] = fma(mv[COL_E], mv[COL_E], fma(mu[COL_E], mu[COL_E], acc[27]));
     }
     JSUB(2);
     if constexpr (ROWS) {
