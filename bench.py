@@ -349,6 +349,50 @@ def ref_example_block(with_cpu=True):
     return out
 
 
+def many_block(contexts=32, rounds=25):
+    """Independent fits in flight together (ccal_fit_many: every context's A4-A9 pipeline enqueued before any wait) against the same
+    contexts fitted one after the other, corners resident: microseconds per fit.  The caller this stands for calibrates many cameras
+    (the loop around src/buildcalibrations.jl:12-26)."""
+    import cameracalibrations_amd as cc
+    from cameracalibrations_amd import synthetic as syn
+    from cameracalibrations_amd.solver import CRITERIA, Solver, reference_flags
+    ex = json.load(open(os.path.join(ROOT, "tests", "golden", "example_corners.json")))
+    ex_img = np.stack([np.array(m, dtype=np.float32).reshape(-1, 2) for m in ex["corners"]])
+    rng = np.random.default_rng(7)
+
+    def problem(name, i):
+        if name == "ref_example":
+            return cc.board_template(ex["n_corners"]), (ex_img + rng.normal(0, 0.05, ex_img.shape)).astype(np.float32), ex["image_size_wh"], 1.0, reference_flags(True)
+        wl = syn.named_workload(name, seed_offset=i)
+        return wl.obj, wl.img, wl.image_size, wl.aspect, wl.flags
+    out = {"contexts": contexts, "what": "us per fit, median over rounds: the contexts' ccal_fit one after the other | one ccal_fit_many over all of them; "
+                                         "different problems of one shape, corners resident, results bit-equal (tests)"}
+    for name in ("ref_example", "C1", "C3"):
+        solvers = []
+        for i in range(contexts):
+            obj, img, size, aspect, flags = problem(name, i)
+            s = Solver(0)
+            s.set_problem(obj, img.shape[0], size, aspect=aspect, flags=flags, max_iter=CRITERIA[0], eps=CRITERIA[1])
+            s.set_image_points(img)
+            solvers.append(s)
+        t_seq, t_many = [], []
+        for rep in range(rounds + 3):
+            t0 = time.perf_counter()
+            for s in solvers:
+                s.fit()
+            t1 = time.perf_counter()
+            cc.fit_many(solvers)
+            t2 = time.perf_counter()
+            t_seq.append((t1 - t0) / contexts)
+            t_many.append((t2 - t1) / contexts)
+        a, b = float(np.median(t_seq[3:])), float(np.median(t_many[3:]))
+        out[name.lower()] = {"us_per_fit_one_at_a_time": 1e6 * a, "us_per_fit_many": 1e6 * b, "speedup": a / b,
+                             "images": int(img.shape[0]), "corners_per_image": int(img.shape[1])}
+        for s in solvers:
+            s.close()
+    return out
+
+
 class BlockFailed(RuntimeError):
     """Raised by EVERY rank at the same point of a block (after an all_agree), so that a per-block try / except never
     lets one rank skip a collective the others enter."""
@@ -999,6 +1043,10 @@ def main():
             out["ref_example"] = ref_example_block(with_cpu=not args.no_cpu_baseline)
         except Exception as exc:      # noqa: BLE001
             out["ref_example"] = {"error": str(exc)}
+        try:
+            out["many_fits"] = many_block()
+        except Exception as exc:      # noqa: BLE001
+            out["many_fits"] = {"error": str(exc)}
         try:
             out["maps"] = maps_block(wl, rf, with_cpu=not args.no_cpu_baseline)
         except Exception as exc:      # noqa: BLE001

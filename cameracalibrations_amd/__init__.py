@@ -6,7 +6,7 @@ from .calibration import (Calibration, RowCol, XYZ, board_template, calculate_er
                           obj2img, rectification)
 from .detect import _detect_corners, detect_corners  # noqa: F401
 from .io import load, save  # noqa: F401
-from .solver import CRITERIA, Solver, device_count, fit_model, reference_flags  # noqa: F401
+from .solver import CRITERIA, Solver, device_count, fit_many, fit_model, fit_models, reference_flags  # noqa: F401
 
-__all__ = ["fit", "fit_corners", "fit_model", "Calibration", "RowCol", "XYZ", "rectification", "calculate_errors",
+__all__ = ["fit", "fit_corners", "fit_model", "fit_models", "fit_many", "Calibration", "RowCol", "XYZ", "rectification", "calculate_errors",
            "obj2img", "board_template", "save", "load", "detect_corners", "Solver", "device_count", "reference_flags", "CRITERIA"]

@@ -85,6 +85,7 @@ SIGNATURES = {
     "ccal_set_extrinsics": (C.c_int, [C.c_void_p, _dp]),
     "ccal_lm_run": (C.c_int, [C.c_void_p]),
     "ccal_fit": (C.c_int, [C.c_void_p]),
+    "ccal_fit_many": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32)]),
     "ccal_set_sweep_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "ccal_set_graph": (C.c_int, [C.c_void_p, C.c_int32]),
     "ccal_set_pose_init": (C.c_int, [C.c_void_p, C.c_int32]),

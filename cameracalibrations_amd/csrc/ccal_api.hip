@@ -1280,33 +1280,94 @@ int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int
 // Initialisation + LM on the problem and image points already set on this context (host copy or device pointer), as
 // one pipeline: every stage is enqueued behind the previous one, the host waits once (the LM's progress word); the
 // initialisation's flags and values are read back in front of the LM's launches, so they have landed by then.
-int ccal_fit(ccal_ctx *c) {
-    if (!c) return fail(CCAL_E_ARG, "ccal_fit: ctx == NULL");
-    if (!c->have_problem || !c->have_img) return fail(CCAL_E_STATE, "ccal_fit: problem / image points not set");
-    const bool guess = (c->flags & CCAL_USE_INTRINSIC_GUESS) != 0;
-    if (guess && !c->have_intr) return fail(CCAL_E_STATE, "ccal_fit: USE_INTRINSIC_GUESS without ccal_set_intrinsics");
-    int rc = CCAL_OK, lm_rc = CCAL_OK;
+// ccal_fit in two halves: everything enqueued (both initialisation stages and the LM's launches) | the one wait, the LM's
+// continuation if its graph was sized for another problem, the checks.  ccal_fit_many runs the first half of every context
+// before the second half of any.
+struct FitPhase { bool guess = false; int rc = CCAL_OK; int lm_rc = CCAL_OK; bool lm_begun = false; std::string err; };
+
+static void fit_begin(ccal_ctx *c, FitPhase &ph) {
+    ph = FitPhase();
+    if (!c) { ph.rc = fail(CCAL_E_ARG, "ccal_fit: ctx == NULL"); ph.err = g_err; return; }
+    if (!c->have_problem || !c->have_img) { ph.rc = fail(CCAL_E_STATE, "ccal_fit: problem / image points not set"); ph.err = g_err; return; }
+    ph.guess = (c->flags & CCAL_USE_INTRINSIC_GUESS) != 0;
+    if (ph.guess && !c->have_intr) { ph.rc = fail(CCAL_E_STATE, "ccal_fit: USE_INTRINSIC_GUESS without ccal_set_intrinsics"); ph.err = g_err; return; }
     c->defer_sync = true;
     do {
-        if (!guess && (rc = ccal_init_intrinsics(c)) < 0) break;
-        if ((rc = ccal_init_extrinsics(c)) < 0) break;
-        lm_rc = ccal_lm_run(c);        // (its first launch carries the init stages' flags and intrinsics to the host)
-        const std::string lm_err = g_err;
+        if (!ph.guess && (ph.rc = ccal_init_intrinsics(c)) < 0) break;
+        if ((ph.rc = ccal_init_extrinsics(c)) < 0) break;
+        ph.lm_rc = lm_begin(c);        // (its first launch carries the init stages' flags and intrinsics to the host)
+        ph.lm_begun = ph.lm_rc == CCAL_OK;
+    } while (0);
+    c->defer_sync = false;
+    if (ph.rc < 0 || ph.lm_rc < 0) ph.err = g_err;
+}
+
+static int fit_end(ccal_ctx *c, FitPhase &ph) {
+    if (!c) { g_err = ph.err; return ph.rc; }
+    int rc = ph.rc;
+    if (rc >= 0) {
+        int lm_rc = ph.lm_rc;
+        if (ph.lm_begun) {
+            (void)hipSetDevice(c->device);
+            lm_rc = lm_wait(c);
+            while (lm_rc == CCAL_OK && lm_unfinished(c))   // the graph was sized for another problem: continue (the next solve re-captures)
+                if ((lm_rc = lm_more(c)) == CCAL_OK) lm_rc = lm_wait(c);
+            if (lm_rc == CCAL_OK) lm_rc = lm_end(c);
+            if (lm_rc < 0) ph.err = g_err;
+        }
         if (lm_rc < 0) {               // (the LM may not have reached its first launch, and did not wait for its own completion)
             (void)finish_init_enqueue(c);
             (void)hipStreamSynchronize(c->stream);
         }
         // initialisation failures explain (and outrank) whatever the LM reported on garbage
-        if ((rc = finish_init_check(c, !guess, true)) < 0) break;
-        if ((rc = lm_rc) < 0) g_err = lm_err;
-    } while (0);
-    c->defer_sync = false;
+        if ((rc = finish_init_check(c, !ph.guess, true)) >= 0 && (rc = lm_rc) < 0) g_err = ph.err;
+    } else {
+        g_err = ph.err;
+    }
     if (rc < 0) {
         const std::string keep = g_err;
         (void)hipStreamSynchronize(c->stream);
         g_err = keep;
     }
     return rc;
+}
+
+int ccal_fit(ccal_ctx *c) {
+    FitPhase ph;
+    fit_begin(c, ph);
+    return fit_end(c, ph);
+}
+
+int ccal_fit_many(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out) {
+    if (n < 0 || (n > 0 && !ctxs)) return fail(CCAL_E_ARG, "ccal_fit_many: bad arguments");
+    for (int a = 0; a < n; a++)
+        for (int b = 0; b < a; b++)
+            if (ctxs[a] && ctxs[a] == ctxs[b]) return fail(CCAL_E_ARG, "ccal_fit_many: a context is listed twice");
+    for (int a = 0; a < n; a++)
+        if (ctxs[a] && (sharded(ctxs[a]) || ctxs[a]->p2p_split))
+            return fail(CCAL_E_STATE, "ccal_fit_many: a context is a shard of a joint fit (its peers' launches would have to be enqueued too)");
+    std::vector<FitPhase> ph((size_t)n);
+    const double t0 = now_s();
+    // (enqueued by this one thread: helper threads enqueueing beside it were measured -- 2 and 4 threads, 32 contexts -- and changed
+    //  nothing: the runtime serialises launch calls.  A pipeline costs the host ~14 us of launch calls, which is what bounds a batch
+    //  of small fits: tools/many_timing.py)
+    for (int a = 0; a < n; a++) fit_begin(ctxs[a], ph[a]);
+    static const bool dbg = getenv("CCAL_DEBUG_TIMING") != nullptr;
+    static double dbg_enq = 0.0; static long dbg_calls = 0, dbg_n = 0;
+    if (dbg) {
+        dbg_enq += now_s() - t0; dbg_n += n;
+        if (++dbg_calls % 20 == 0) { fprintf(stderr, "[ccal] fit_many: enqueue %.2f us per context over the last 20 calls\n", 1e6 * dbg_enq / (double)dbg_n); dbg_enq = 0.0; dbg_n = 0; }
+    }
+    int worst = CCAL_OK;
+    std::string worst_err;
+    for (int a = 0; a < n; a++) {
+        const int rc = fit_end(ctxs[a], ph[a]);
+        if (status_out) status_out[a] = rc;
+        if (rc < 0 && worst >= 0) { worst = rc; worst_err = "context " + std::to_string(a) + ": " + g_err; }
+        else if (rc > worst && worst >= 0) worst = rc;
+    }
+    if (worst < 0) g_err = worst_err;
+    return worst;
 }
 
 static MultiSet *multi_get(int n_dev, const int32_t *dev_ids) {

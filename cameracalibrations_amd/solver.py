@@ -306,6 +306,51 @@ def calibrate_multi(obj, img, image_size, devices, aspect=1.0, flags=0, max_iter
     return status, d
 
 
+def fit_many(solvers, check=True):
+    """`Solver.fit()` of several INDEPENDENT problems, one Solver each (ccal_fit_many): every pipeline is enqueued on its context's
+    stream before any is waited for, so the GPU overlaps them.  Returns the per-solver statuses; results through each
+    `Solver.result()`.  check=False: failures are reported in the list (negative codes) instead of raised."""
+    n = len(solvers)
+    hs = (C.c_void_p * n)(*[s._h for s in solvers])
+    st = (C.c_int32 * n)()
+    rc = F.lib().ccal_fit_many(hs, n, st)
+    if check:
+        F.check(rc)
+    return [int(v) for v in st]
+
+
+_pool = {}    # device -> Solvers kept for fit_models (a context holds its buffers and captured graph between calls)
+
+
+def fit_models(sz, objpoints, imgpointsss, n_corners, with_distortion, aspect, device=0):
+    """`fit_model` (src/detect_fit.jl:27-61) for several calibrations at once -- the loop a caller with many cameras runs around
+    src/buildcalibrations.jl:12-26: imgpointsss = one list / array of per-image corners PER calibration (the template, image size,
+    flags and aspect are shared, as one caller's are).  Returns a list of fit_model's namespaces, the same values fit_model
+    returns for each set on its own."""
+    P = int(n_corners[0]) * int(n_corners[1])
+    obj = np.asarray(objpoints, dtype=np.float32).reshape(P, 3)
+    pool = _pool.setdefault(int(device), [])
+    while len(pool) < len(imgpointsss):
+        pool.append(Solver(device))
+    used = pool[:len(imgpointsss)]
+    for s, pts in zip(used, imgpointsss):
+        if isinstance(pts, np.ndarray):
+            img = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, P, 2)
+        else:
+            img = np.stack([np.asarray(m, dtype=np.float32).reshape(P, 2) for m in pts])
+        s.set_problem(obj, img.shape[0], (int(sz[0]), int(sz[1])), aspect=float(aspect), flags=reference_flags(with_distortion),
+                      max_iter=CRITERIA[0], eps=CRITERIA[1])
+        s.set_image_points(img)
+    fit_many(used)
+    out = []
+    for s in used:
+        r = s.result()
+        out.append(SimpleNamespace(k=float(r["intr"][4]), Rs=list(r["rvecs"]), ts=list(r["tvecs"]), frow=float(r["intr"][0]),
+                                   fcol=float(r["intr"][1]), crow=float(r["intr"][2]), ccol=float(r["intr"][3]), rms=r["rms"],
+                                   iters=r["iters"], stats={k: v for k, v in r.items() if k not in ("intr", "K4", "dist5", "rvecs", "tvecs")}))
+    return out
+
+
 def debug_multi_set_epoch(devices, epoch):
     """Diagnostics: set the solve sequence number of every shard of this thread's cached `calibrate_multi` device set."""
     devs = (C.c_int32 * len(devices))(*[int(d) for d in devices])

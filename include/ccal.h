@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CCAL_VERSION 103 /* 0.1.3: ccal_stats.sweep_form (was padding); 0.1.2: ccal_p2p_export2 / ccal_p2p_connect2, ccal_p2p_set_exchange mode 2 */
+#define CCAL_VERSION 104 /* 0.1.4: ccal_fit_many; 0.1.3: ccal_stats.sweep_form (was padding); 0.1.2: ccal_p2p_export2 / ccal_p2p_connect2, ccal_p2p_set_exchange mode 2 */
 
 /* status codes */
 #define CCAL_OK            0
@@ -197,6 +197,14 @@ int  ccal_set_pose_init(ccal_ctx *ctx, int32_t mode);
  * enqueued back to back and the host waits once.  Same results as the three calls above; their per-stage times in
  * ccal_stats then only cover the enqueueing. */
 int  ccal_fit(ccal_ctx *ctx);
+/* ccal_fit for n INDEPENDENT problems, one context each (a caller that calibrates many cameras: the loop around
+ * src/buildcalibrations.jl:12-26): every context's pipeline is enqueued on its own stream before any is waited for, so the
+ * GPU overlaps them -- a fit of a few images occupies a few compute units and spends most of its time in launch and
+ * hand-off latency.  Contexts may live on different devices; shards of a joint fit are refused (CCAL_E_STATE).  Each
+ * context ends exactly as after its own ccal_fit (same bits; results through ccal_get_result).  status_out[i] (may be
+ * NULL) = what ccal_fit would have returned for context i; the return value is the first failure, else the largest
+ * warning; ccal_last_error() then names that context. */
+int  ccal_fit_many(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out);
 /* Bracket every sweep launch of the next ccal_lm_run calls with a HIP event pair on the launch
  * stream and report the mean in ccal_stats.sweep_us (roofline figure of bench.py). */
 int  ccal_set_sweep_timing(ccal_ctx *ctx, int32_t enable);

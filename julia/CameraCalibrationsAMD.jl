@@ -87,6 +87,42 @@ mutable struct Context
     end
 end
 
+"""
+    fit_models(sz, objpoints, imgpointsss, n_corners, with_distortion, aspect)
+
+`fit_model` for several calibrations at once (one vector of per-image corner matrices per calibration; template, image size and
+flags shared): one context per calibration, every pipeline enqueued before any is waited for (`ccal_fit_many`) -- the loop a
+caller with many cameras runs around src/buildcalibrations.jl:12-26.  Returns a vector of `fit_model`'s NamedTuples.
+"""
+function fit_models(sz, objpoints, imgpointsss, n_corners, with_distortion, aspect; device = 0)
+    P = prod(n_corners)
+    obj = Float32.(reshape(reinterpret(reshape, eltype(eltype(objpoints)), vec(objpoints)), 3, P))   # [3,P]
+    flags = ZERO_TANGENT_DIST | FIX_K3 | FIX_K2 | (with_distortion ? 0x0 : FIX_K1) | FIX_ASPECT_RATIO
+    ctxs = [Context(device) for _ in imgpointsss]
+    for (c, imgpointss) in zip(ctxs, imgpointsss)
+        N = length(imgpointss)
+        img = Array{Float32}(undef, 2, P, N)                                                     # [2,P,N]
+        for (i, m) in enumerate(imgpointss), (p, rc) in enumerate(vec(m))
+            img[1, p, i] = rc[1]; img[2, p, i] = rc[2]
+        end
+        check(ccall((:ccal_set_problem, LIB), Int32,
+                    (Ptr{Cvoid}, Ptr{Float32}, Int32, Int32, Int32, Int32, Float64, UInt32, Int32, Float64),
+                    c.h, obj, P, N, sz[1], sz[2], Float64(aspect), flags, CRITERIA[1], CRITERIA[2]))
+        check(ccall((:ccal_set_image_points, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}), c.h, img))
+    end
+    hs = [c.h for c in ctxs]
+    GC.@preserve ctxs check(ccall((:ccal_fit_many, LIB), Int32, (Ptr{Ptr{Cvoid}}, Int32, Ptr{Int32}), hs, length(hs), C_NULL))
+    return map(zip(ctxs, imgpointsss)) do (c, imgpointss)
+        N = length(imgpointss)
+        intr = zeros(Float64, 9); rvecs = zeros(Float64, 3, N); tvecs = zeros(Float64, 3, N)
+        check(ccall((:ccal_get_result, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
+                    c.h, intr, rvecs, tvecs, C_NULL))
+        frow, fcol, crow, ccol = intr[1:4]
+        k = intr[5]
+        (; k, Rs = [rvecs[:, i] for i in 1:N], ts = [tvecs[:, i] for i in 1:N], frow, fcol, crow, ccol)
+    end
+end
+
 function project(c::Context, xyz::Matrix{Float64}, f, cc, k, rvec, tvec, checker_size)
     M = size(xyz, 2); out = zeros(Float64, 2, M)
     check(ccall((:ccal_project, LIB), Int32,

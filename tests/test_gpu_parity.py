@@ -1304,3 +1304,60 @@ def test_sweep_form_names_the_kernel_that_ran():
         with _solver(wl, REF) as s:
             _, r = s.calibrate()
         assert r["sweep_form"] == want, (name, n, hex(r["sweep_form"]))
+
+
+def test_fit_many_equals_one_fit_at_a_time(golden_dir):
+    """ccal_fit_many: the pipelines of several independent problems enqueued on their contexts' streams before any is waited for.
+    Every context ends with the bits its own ccal_fit gives (exact accumulators: nothing depends on what else the GPU runs), a
+    failing problem (a non-planar template) is reported in its slot and by the call without disturbing the others, a repeated
+    call reuses the captured graphs, and fit_models returns what fit_model returns for each set of the reference's example."""
+    from cameracalibrations_amd import _ffi as F, fit_many, fit_models
+    specs = [("C1", 7, REF), ("C2", 40, REF), ("REF", 6, REF), ("C5", 5, REF), ("C2", 300, TIGHT), ("C1", 100, REF), ("C2", 3, REF),
+             ("C5", 40, REF), ("REF", 129, REF)]
+    wls = [syn.named_workload(n, n_images=k, seed_offset=i) for i, (n, k, _) in enumerate(specs)]
+    alone = []
+    for wl, (_, _, crit) in zip(wls, specs):
+        with _solver(wl, crit) as s:
+            st = s.fit()
+            alone.append((st, s.result()))
+    solvers = [_solver(wl, crit) for wl, (_, _, crit) in zip(wls, specs)]
+    try:
+        for rep in range(3):
+            sts = fit_many(solvers)
+            for s, st, (st0, r0) in zip(solvers, sts, alone):
+                r = s.result()
+                assert st == st0 and r["iters"] == r0["iters"] and r["sweeps"] == r0["sweeps"]
+                for k in ("intr", "rvecs", "tvecs"):
+                    assert np.array_equal(r[k], r0[k]), k
+                assert r["rms"] == r0["rms"]
+        # one bad problem among them
+        bent = wls[1].obj.copy()
+        bent[3, 2] = 0.5
+        solvers[1].set_problem(bent, wls[1].n_images, wls[1].image_size, flags=wls[1].flags)
+        solvers[1].set_image_points(wls[1].img)
+        with pytest.raises(F.CcalError) as e:
+            fit_many(solvers)
+        assert e.value.code == F.E_NONPLANAR and "context 1" in str(e.value)
+        sts = fit_many(solvers, check=False)
+        assert sts[1] == F.E_NONPLANAR and all(st == st0 for i, (st, (st0, _)) in enumerate(zip(sts, alone)) if i != 1)
+        for i, (s, (_, r0)) in enumerate(zip(solvers, alone)):
+            if i != 1:
+                assert np.array_equal(s.result()["intr"], r0["intr"])
+        with pytest.raises(F.CcalError) as e:
+            fit_many([solvers[0], solvers[0]])
+        assert e.value.code == F.E_ARG
+        assert fit_many([]) == []
+    finally:
+        for s in solvers:
+            s.close()
+    with open(os.path.join(golden_dir, "example_corners.json")) as f:
+        ex = json.load(f)
+    from cameracalibrations_amd import board_template
+    obj = board_template(ex["n_corners"])
+    imgs = [np.array(m, dtype=np.float64) for m in ex["corners"]]
+    sets = [imgs, imgs[:4], imgs[1:], imgs[::-1]]
+    many = fit_models(ex["image_size_wh"], obj, sets, ex["n_corners"], True, 1)
+    for sub, a in zip(sets, many):
+        b = fit_model(ex["image_size_wh"], obj, sub, ex["n_corners"], True, 1)
+        assert (a.frow, a.fcol, a.crow, a.ccol, a.k, a.rms, a.iters) == (b.frow, b.fcol, b.crow, b.ccol, b.k, b.rms, b.iters)
+        assert np.array_equal(np.array(a.Rs), np.array(b.Rs)) and np.array_equal(np.array(a.ts), np.array(b.ts))
