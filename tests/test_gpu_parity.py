@@ -1347,6 +1347,36 @@ def test_fit_many_equals_one_fit_at_a_time(golden_dir):
             fit_many([solvers[0], solvers[0]])
         assert e.value.code == F.E_ARG
         assert fit_many([]) == []
+        # Contexts that live on between calls: new corners behind the same pointers, a new problem, calls of ccal_fit in between and
+        # a changed pose-initialisation mode all have to end with the bits of a fresh context's own fit.
+        solvers[1].set_problem(wls[1].obj, wls[1].n_images, wls[1].image_size, aspect=wls[1].aspect, flags=wls[1].flags,
+                               max_iter=specs[1][2][0], eps=specs[1][2][1])
+        solvers[1].set_image_points(wls[1].img)
+        for rep in range(5):
+            if rep == 2:                                  # other corners for two of them, one back on its own ccal_fit in between
+                for i in (0, 5):
+                    wls[i] = syn.named_workload(specs[i][0], n_images=specs[i][1], seed_offset=100 + i)
+                    solvers[i].set_image_points(wls[i].img)
+                    with _solver(wls[i], specs[i][2]) as s:
+                        alone[i] = (s.fit(), s.result())
+                solvers[3].fit()
+            if rep == 3:                                  # a smaller problem in a context that has held a larger one
+                wls[4] = syn.named_workload("C2", n_images=120, seed_offset=55)
+                solvers[4].set_problem(wls[4].obj, 120, wls[4].image_size, aspect=wls[4].aspect, flags=wls[4].flags, max_iter=REF[0], eps=REF[1])
+                solvers[4].set_image_points(wls[4].img)
+                with _solver(wls[4], REF) as s:
+                    alone[4] = (s.fit(), s.result())
+            if rep == 4:
+                solvers[2].set_pose_init(0)
+                with _solver(wls[2], specs[2][2]) as s:
+                    s.set_pose_init(0)
+                    alone[2] = (s.fit(), s.result())
+            sts = fit_many(solvers)
+            for i, (s, st, (st0, r0)) in enumerate(zip(solvers, sts, alone)):
+                r = s.result()
+                assert st == st0 and r["iters"] == r0["iters"] and r["sweeps"] == r0["sweeps"], (rep, i)
+                for k in ("intr", "rvecs", "tvecs"):
+                    assert np.array_equal(r[k], r0[k]), (rep, i, k)
     finally:
         for s in solvers:
             s.close()
