@@ -1552,8 +1552,24 @@ static constexpr size_t STAGE_MAX = 16u << 20;
 // Wait for everything enqueued on the context's stream so far: a one-thread kernel behind it raises a sequence number
 // in pinned memory and the host spins on that word (a blocking stream synchronisation costs tens to hundreds of
 // microseconds of wake-up latency per call); after 2 ms of spinning the wait becomes a stream synchronisation.
+static unsigned long long *pin_flag(ccal_ctx *c) { return reinterpret_cast<unsigned long long *>(static_cast<char *>(c->h_pin) + PIN_BYTES); }
+
+// wait for the completion word to take the value `want` (written by k_signal, or by a one-workgroup map kernel itself)
+static int spin_flag(ccal_ctx *c, unsigned long long want) {
+    volatile unsigned long long *flag = pin_flag(c);
+    const double t_end = now_s() + 2e-3;
+    bool seen = false;
+    for (long spins = 0; !seen; spins++) {
+        seen = *flag == want;
+        if (!seen && (spins & 255) == 255 && now_s() > t_end) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) HIPCHK(hipStreamSynchronize(c->stream));
+    return CCAL_OK;
+}
+
 static int signal_and_spin(ccal_ctx *c) {
-    volatile unsigned long long *flag = reinterpret_cast<volatile unsigned long long *>(static_cast<char *>(c->h_pin) + PIN_BYTES);
+    volatile unsigned long long *flag = pin_flag(c);
     const unsigned long long want = ++c->pin_seq;
     HIPCHK(launch_signal(c->stream, const_cast<unsigned long long *>(flag), want));
     const double t_end = now_s() + 2e-3;
@@ -1623,8 +1639,11 @@ static int map_many(ccal_ctx *c, const double *in, int32_t M, int32_t N, bool pe
         HIPCHK(hipMemcpyAsync(d_rt, h_rt, 8 * n_rt, hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(d_in, in, 8 * n_in, hipMemcpyHostToDevice, c->stream));
     }
-    if (forward) HIPCHK(launch_map_forward(c->stream, d_in, per_image ? (long long)3 * M : 0ll, d_out, M, N, mi, d_rt));
-    else HIPCHK(launch_map_inverse(c->stream, d_in, d_out, M, N, mi, d_rt));
+    // a point-wise call (one workgroup on the pinned block): the map kernel writes the completion word itself -- one launch
+    const bool own_flag = small && map_is_one_workgroup(M, N);
+    const unsigned long long want = own_flag ? ++c->pin_seq : 0ull;
+    if (forward) HIPCHK(launch_map_forward(c->stream, d_in, per_image ? (long long)3 * M : 0ll, d_out, M, N, mi, d_rt, own_flag ? pin_flag(c) : nullptr, want));
+    else HIPCHK(launch_map_inverse(c->stream, d_in, d_out, M, N, mi, d_rt, own_flag ? pin_flag(c) : nullptr, want));
     if (!small) {
         HIPCHK(hipMemcpyAsync(staged ? static_cast<void *>(hs + b_rt + b_in) : static_cast<void *>(out), d_out, 8 * n_out,
                               hipMemcpyDeviceToHost, c->stream));
@@ -1633,7 +1652,7 @@ static int map_many(ccal_ctx *c, const double *in, int32_t M, int32_t N, bool pe
         return CCAL_OK;
     }
     // zero-copy path: wait for the map kernel without a stream synchronisation
-    const int rc = signal_and_spin(c);
+    const int rc = own_flag ? spin_flag(c, want) : signal_and_spin(c);
     if (rc) return rc;
     memcpy(out, d_out, 8 * n_out);
     return CCAL_OK;

@@ -88,10 +88,12 @@ hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const fl
 // ccal_maps.hip -- RowCol <-> XYZ maps and the four RMS metrics
 struct MapIntr { double f[2], c[2], k, cs; };   // intrinsic map parameters + checker_size, a kernel argument by value
 // [3, M, N] -> [2, M, N] (xyz_stride = 3 M) or one [3, M] template through N poses (xyz_stride = 0); rt [6, N]
+// flag != nullptr (one-workgroup launches only, map_is_one_workgroup): the kernel writes flag_value there (system scope) after its results
+bool map_is_one_workgroup(int M, int N);
 hipError_t launch_map_forward(hipStream_t stream, const double *xyz, long long xyz_stride, double *rc, int M, int N,
-                              const MapIntr &in, const double *rt);
+                              const MapIntr &in, const double *rt, unsigned long long *flag = nullptr, unsigned long long flag_value = 0);
 hipError_t launch_map_inverse(hipStream_t stream, const double *rc, double *xyz, int M, int N, const MapIntr &in,
-                              const double *rt);
+                              const double *rt, unsigned long long *flag = nullptr, unsigned long long flag_value = 0);
 hipError_t launch_signal(hipStream_t stream, unsigned long long *flag, unsigned long long value);   // pinned completion word
 // n 32-bit words src -> dst by a kernel on `stream` (src: pinned, device-mapped host memory a small call staged its inputs in)
 hipError_t launch_copy_words(hipStream_t stream, const void *src, void *dst, size_t n_words);

@@ -21,11 +21,20 @@ namespace ccal {
 // Point streams are [3, M, N] / [2, M, N] (image index = blockIdx.y); xyz_stride = 0 maps ONE [3, M] template
 // through every image's pose (what calculate_errors and the plots do, src/buildcalibrations.jl:29).
 // (the image index strides over gridDim.y: a grid's y extent is capped at 65535, the image count is not)
+// flag (one-workgroup launches on pinned buffers only): the completion word the host spins on, written by the map kernel itself once
+// its results have left the device -- a point-wise call is then ONE launch (no k_signal behind it).
+__device__ __forceinline__ void map_done(unsigned long long *flag, unsigned long long value) {
+    if (flag == nullptr) return;                  // (uniform)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(256) void k_map_forward(const double *__restrict__ xyz, long long xyz_stride, double *__restrict__ rc,
-                                                      int M, int N, const MapIntr in, const double *__restrict__ rt) {
+                                                      int M, int N, const MapIntr in, const double *__restrict__ rt,
+                                                      unsigned long long *flag, unsigned long long flag_value) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    for (int img = blockIdx.y; img < N; img += gridDim.y) {
+    for (int img = blockIdx.y; i < M && img < N; img += gridDim.y) {
         const double *e = rt + (size_t)6 * img;
         const double r[3] = {e[0], e[1], e[2]}, t[3] = {e[3], e[4], e[5]};
         double R[9];
@@ -38,13 +47,14 @@ __global__ __launch_bounds__(256) void k_map_forward(const double *__restrict__ 
         dst[2 * i] = o[0];
         dst[2 * i + 1] = o[1];
     }
+    map_done(flag, flag_value);
 }
 
 __global__ __launch_bounds__(256) void k_map_inverse(const double *__restrict__ rc, double *__restrict__ xyz, int M, int N,
-                                                      const MapIntr in, const double *__restrict__ rt) {
+                                                      const MapIntr in, const double *__restrict__ rt,
+                                                      unsigned long long *flag, unsigned long long flag_value) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= M) return;
-    for (int img = blockIdx.y; img < N; img += gridDim.y) {
+    for (int img = blockIdx.y; i < M && img < N; img += gridDim.y) {
         const double *e = rt + (size_t)6 * img;
         const double r[3] = {e[0], e[1], e[2]}, t[3] = {e[3], e[4], e[5]};
         double R[9], ti[3];
@@ -60,6 +70,7 @@ __global__ __launch_bounds__(256) void k_map_inverse(const double *__restrict__ 
         dst[3 * i + 1] = o[1];
         dst[3 * i + 2] = o[2];
     }
+    map_done(flag, flag_value);
 }
 
 // One workgroup per image: the four sums of calculate_errors for that image.
@@ -222,14 +233,18 @@ hipError_t launch_signal(hipStream_t stream, unsigned long long *flag, unsigned 
     return hipGetLastError();
 }
 
+bool map_is_one_workgroup(int M, int N) { return M <= 256 && N == 1; }
 hipError_t launch_map_forward(hipStream_t stream, const double *xyz, long long xyz_stride, double *rc, int M, int N,
-                              const MapIntr &in, const double *rt) {
-    hipLaunchKernelGGL(k_map_forward, dim3((M + 255) / 256, N < 65535 ? N : 65535), dim3(256), 0, stream, xyz, xyz_stride, rc, M, N, in, rt);
+                              const MapIntr &in, const double *rt, unsigned long long *flag, unsigned long long flag_value) {
+    if (flag != nullptr && !map_is_one_workgroup(M, N)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_map_forward, dim3((M + 255) / 256, N < 65535 ? N : 65535), dim3(256), 0, stream, xyz, xyz_stride, rc, M, N, in, rt,
+                       flag, flag_value);
     return hipGetLastError();
 }
 hipError_t launch_map_inverse(hipStream_t stream, const double *rc, double *xyz, int M, int N, const MapIntr &in,
-                              const double *rt) {
-    hipLaunchKernelGGL(k_map_inverse, dim3((M + 255) / 256, N < 65535 ? N : 65535), dim3(256), 0, stream, rc, xyz, M, N, in, rt);
+                              const double *rt, unsigned long long *flag, unsigned long long flag_value) {
+    if (flag != nullptr && !map_is_one_workgroup(M, N)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_map_inverse, dim3((M + 255) / 256, N < 65535 ? N : 65535), dim3(256), 0, stream, rc, xyz, M, N, in, rt, flag, flag_value);
     return hipGetLastError();
 }
 hipError_t launch_errors(hipStream_t stream, const double *obj, const double *img, const MapIntr &in,
