@@ -136,6 +136,7 @@ struct ccal_ctx {
     // small drop-in calls (ccal_calibrate): inputs staged in the pinned block and copied by a kernel, poses written to it by the launch
     // that ends the solve -- no copy command, no read-back launch, one wait.  Layout of h_pin: template | corners | poses
     bool small_call = false;
+    size_t obj_staged = 0;        // words of the template waiting in the pinned block for the corners' copy launch (small calls only)
     double *host_poses = nullptr;
     bool use_solo = true;         // fits of a few images on one GPU run all their trials in ONE launch (CCAL_NO_SOLO=1: launch per trial)
     bool run_solo = false;
@@ -477,7 +478,7 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
     }
     if (c->small_call && sizeof(float) * 3 * P <= PIN_OBJ_BYTES) {
         memcpy(static_cast<char *>(c->h_pin) + PIN_OBJ_OFF, obj, sizeof(float) * 3 * P);
-        HIPCHK(launch_copy_words(c->stream, static_cast<char *>(c->h_pin) + PIN_OBJ_OFF, c->d_obj, (size_t)3 * P));
+        c->obj_staged = (size_t)3 * P;     // (copied by the launch that copies the corners: ccal_set_image_points follows at once)
     } else {
         HIPCHK(hipMemcpyAsync(c->d_obj, obj, sizeof(float) * 3 * P, hipMemcpyHostToDevice, c->stream));
     }
@@ -520,8 +521,14 @@ int ccal_set_image_points(ccal_ctx *c, const float *img_host) {
     }
     if (c->small_call && need <= PIN_IMG_BYTES) {
         memcpy(static_cast<char *>(c->h_pin) + PIN_IMG_OFF, img_host, need);
-        HIPCHK(launch_copy_words(c->stream, static_cast<char *>(c->h_pin) + PIN_IMG_OFF, c->d_img_own, need / 4));
+        HIPCHK(launch_copy_words2(c->stream, static_cast<char *>(c->h_pin) + PIN_OBJ_OFF, c->d_obj, c->obj_staged,
+                                  static_cast<char *>(c->h_pin) + PIN_IMG_OFF, c->d_img_own, need / 4));
+        c->obj_staged = 0;
     } else {
+        if (c->obj_staged) {
+            HIPCHK(launch_copy_words(c->stream, static_cast<char *>(c->h_pin) + PIN_OBJ_OFF, c->d_obj, c->obj_staged));
+            c->obj_staged = 0;
+        }
         HIPCHK(hipMemcpyAsync(c->d_img_own, img_host, need, hipMemcpyHostToDevice, c->stream));
     }
     if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));
@@ -1227,7 +1234,7 @@ int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int
     c->host_poses = (c->small_call && (rvecs || tvecs)) ? reinterpret_cast<double *>(static_cast<char *>(c->h_pin) + PIN_POSE_OFF) : nullptr;
     do {
         if ((rc = ccal_set_problem(c, obj, P, N, width, height, aspect, flags, max_iter, eps)) < 0) break;
-        if ((rc = ccal_set_image_points(c, img)) < 0) break;
+        if ((rc = ccal_set_image_points(c, img)) < 0) { c->have_problem = false; c->obj_staged = 0; break; }   // (the template was not uploaded)
         if (guess) {
             if (!K4 || !dist5) { rc = fail(CCAL_E_ARG, "ccal_calibrate: intrinsic guess requested but K4/dist5 NULL"); break; }
             const double g[9] = {K4[0], K4[1], K4[2], K4[3], dist5[0], dist5[1], dist5[2], dist5[3], dist5[4]};

@@ -97,6 +97,7 @@ hipError_t launch_map_inverse(hipStream_t stream, const double *rc, double *xyz,
 hipError_t launch_signal(hipStream_t stream, unsigned long long *flag, unsigned long long value);   // pinned completion word
 // n 32-bit words src -> dst by a kernel on `stream` (src: pinned, device-mapped host memory a small call staged its inputs in)
 hipError_t launch_copy_words(hipStream_t stream, const void *src, void *dst, size_t n_words);
+hipError_t launch_copy_words2(hipStream_t stream, const void *src1, void *dst1, size_t n1, const void *src2, void *dst2, size_t n2);
 // intr[9], fail[4] (device) -> pinned host memory, by a kernel on `stream`
 hipError_t launch_init_readback(hipStream_t stream, const double *intr, const int *fail, double *host_intr, int *host_fail);
 struct RectPar { double v[16]; };   // f0 f1 c0 c1 k rvec(3) tvec(3) checker_size ratio index_offset, by value

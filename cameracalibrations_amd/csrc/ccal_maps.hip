@@ -221,6 +221,23 @@ __global__ __launch_bounds__(256) void k_copy_words(const uint32_t *__restrict__
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
+// two segments in one launch (a small drop-in call's template and corners, both staged in the pinned block)
+__global__ __launch_bounds__(256) void k_copy_words2(const uint32_t *__restrict__ src1, uint32_t *__restrict__ dst1, size_t n1,
+                                                      const uint32_t *__restrict__ src2, uint32_t *__restrict__ dst2, size_t n2) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1 + n2; i += (size_t)gridDim.x * blockDim.x) {
+        if (i < n1) dst1[i] = src1[i];
+        else dst2[i - n1] = src2[i - n1];
+    }
+}
+
+hipError_t launch_copy_words2(hipStream_t stream, const void *src1, void *dst1, size_t n1, const void *src2, void *dst2, size_t n2) {
+    if (n1 + n2 == 0) return hipSuccess;
+    const int grid = (int)std::min<size_t>((n1 + n2 + 255) / 256, 64);
+    hipLaunchKernelGGL(k_copy_words2, dim3(grid), dim3(256), 0, stream, static_cast<const uint32_t *>(src1), static_cast<uint32_t *>(dst1), n1,
+                       static_cast<const uint32_t *>(src2), static_cast<uint32_t *>(dst2), n2);
+    return hipGetLastError();
+}
+
 hipError_t launch_copy_words(hipStream_t stream, const void *src, void *dst, size_t n_words) {
     if (n_words == 0) return hipSuccess;
     const int grid = (int)std::min<size_t>((n_words + 255) / 256, 64);

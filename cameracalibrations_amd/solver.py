@@ -366,23 +366,21 @@ def fit_model(sz, objpoints, imgpointss, n_corners, with_distortion, aspect, dev
     returns a namespace (k, Rs, ts, frow, fcol, crow, ccol) like the NamedTuple at :60.
     """
     P = int(n_corners[0]) * int(n_corners[1])
-    obj = np.asarray(objpoints, dtype=np.float32).reshape(P, 3)
-    if isinstance(imgpointss, np.ndarray):           # already one array of all images' corners
+    obj = np.ascontiguousarray(objpoints, dtype=np.float32).reshape(P, 3)
+    try:                                             # one array of all images' corners, or same-shaped per-image arrays: one conversion
         img = np.ascontiguousarray(imgpointss, dtype=np.float32).reshape(-1, P, 2)
-    else:
+    except ValueError:
         img = np.stack([np.asarray(m, dtype=np.float32).reshape(P, 2) for m in imgpointss])
-    K4 = np.zeros(4)
-    dist5 = np.zeros(5)
     N = img.shape[0]
-    rv, tv = np.zeros((N, 3)), np.zeros((N, 3))
-    rms, iters = C.c_double(0), C.c_int32(0)
+    res = np.zeros(10 + 6 * N)                       # K4 | dist5 | rms | rvecs [N,3] | tvecs [N,3]: one allocation, one address
+    K4, dist5, rv, tv = res[0:4], res[4:9], res[10:10 + 3 * N].reshape(N, 3), res[10 + 3 * N:].reshape(N, 3)
+    iters = C.c_int32(0)
     st = F.Stats()
-    op, ip = F.f32(obj)[1], F.f32(img)[1]
-    dp = F._dp
-    F.check(F.lib().ccal_calibrate(op, ip, P, N, int(sz[0]), int(sz[1]), float(aspect),
-                                   reference_flags(with_distortion), CRITERIA[0], CRITERIA[1], int(device),
-                                   K4.ctypes.data_as(dp), dist5.ctypes.data_as(dp), rv.ctypes.data_as(dp),
-                                   tv.ctypes.data_as(dp), C.byref(rms), C.byref(iters), C.byref(st)))
+    base = res.ctypes.data
+    F.check(F.raw("ccal_calibrate")(obj.ctypes.data, img.ctypes.data, P, N, int(sz[0]), int(sz[1]), float(aspect),
+                                    reference_flags(with_distortion), CRITERIA[0], CRITERIA[1], int(device),
+                                    base, base + 32, base + 80, base + 80 + 24 * N, base + 72, C.addressof(iters), C.addressof(st)))
+    rms = SimpleNamespace(value=float(res[9]))
     return SimpleNamespace(k=float(dist5[0]), Rs=list(rv), ts=list(tv),      # per-image vectors (rows of the two result arrays)
                            frow=float(K4[0]), fcol=float(K4[1]), crow=float(K4[2]), ccol=float(K4[3]),
                            rms=rms.value, iters=iters.value, stats=st.asdict())
