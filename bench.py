@@ -730,9 +730,9 @@ def latency_floor(P):
 
 
 def kernel_name(form, kind=1):
-    """the k_lm_trial instantiation as rocprofv3 prints it, from ccal_stats.sweep_form (FLOW | LOOP << 4 | WPI << 8 | SOLO << 12)"""
-    return "ccal::k_lm_trial<%d, %s, %d, %d, %s>" % (form & 15, "true" if (form >> 4) & 1 else "false", kind, (form >> 8) & 15,
-                                                     "true" if (form >> 12) & 1 else "false")
+    """the k_lm_trial instantiation as rocprofv3 prints it, from ccal_stats.sweep_form (FLOW | LOOP << 4 | WPI << 8 | SOLO << 12 | MULTI << 16)"""
+    tf = lambda b: "true" if b else "false"  # noqa: E731
+    return "ccal::k_lm_trial<%d, %s, %d, %d, %s, %s>" % (form & 15, tf((form >> 4) & 1), kind, (form >> 8) & 15, tf((form >> 12) & 1), tf((form >> 16) & 1))
 
 
 def roofline_block(N_rank, P, K, sweep_us, n_timed, b2b_us, events_ms_per_step, kernel, median_us=None):

@@ -127,6 +127,9 @@ struct ccal_ctx {
         int N, P, batch, R, wpi;
         LmInit init;
     } graph_key{};
+    bool run_merged = false;      // this solve's launches were merged with other contexts' (ccal_stats.sweep_form bit 16)
+    bool recording = false;       // ccal_fit_many is recording this context's launches for a merged launch (kernel by kernel, no graph)
+    bool use_merge = true;        // (CCAL_NO_MERGE=1: ccal_fit_many enqueues every context's pipeline on its own stream)
     bool defer_sync = false;      // one-shot path: stage syncs and checks are batched at the end
     double dbg_enqueue_s = 0, dbg_total_s = 0;
     int dbg_runs = 0;
@@ -237,6 +240,7 @@ int ccal_create(int device, ccal_ctx **out) {
     const char *g = getenv("CCAL_NO_GRAPH");
     if (g && atoi(g) != 0) c->use_graph = false;
     if (const char *so = getenv("CCAL_NO_SOLO")) c->use_solo = atoi(so) == 0;
+    if (const char *so = getenv("CCAL_NO_MERGE")) c->use_merge = atoi(so) == 0;
     const char *sp = getenv("CCAL_NO_SPIN");
     if (sp && atoi(sp) != 0) c->spin_wait = false;
     if (const char *hm = getenv("CCAL_INIT_HMODE")) {       // experiments: 0 = OpenCV's own sequence (DLT + polish), 1, 2
@@ -938,6 +942,7 @@ static int lm_prepare(ccal_ctx *c) {
     }
     c->acc_dirty = true;               // until this solve is seen to have ended with its terminating launch
     c->run_graphed = false;
+    c->run_merged = c->recording;
     return CCAL_OK;
 }
 
@@ -959,7 +964,7 @@ static int lm_begin(ccal_ctx *c) {
         c->dbg_enqueue_s += now_s() - t_enq0;
         return CCAL_OK;
     }
-    c->run_graphed = c->use_graph && !c->time_sweeps && (!sharded(c) || via_p2p(c));
+    c->run_graphed = c->use_graph && !c->recording && !c->time_sweeps && (!sharded(c) || via_p2p(c));
     if (c->run_graphed) {
         ccal_ctx::GraphKey key;
         memset(&key, 0, sizeof key);
@@ -1023,7 +1028,7 @@ static int lm_end(ccal_ctx *c) {
     c->stats.rejected = r.rejected; c->stats.lambda_lg10 = r.lambda_lg10; c->stats.n_bad = r.n_bad;
     c->stats.final_err = r.prev_err; c->stats.rel_step = r.rel_step;
     c->stats.rms = std::sqrt(r.prev_err / ((double)r.N_global * (double)c->P));
-    c->stats.sweep_form = lm_sweep_form(c->N, c->wpi, via_p2p(c), c->run_solo);
+    c->stats.sweep_form = lm_sweep_form(c->N, c->wpi, via_p2p(c), c->run_solo) | (c->run_merged ? 1 << 16 : 0);
     c->stats.sweep_us = 0.0;
     c->stats.timed_sweeps = 0;
     c->stats.solve_kernels_us = 0.0;
@@ -1345,6 +1350,161 @@ int ccal_fit(ccal_ctx *c) {
     return fit_end(c, ph);
 }
 
+// ---- ccal_fit_many: merged launches ---------------------------------------------------------------------------------------------
+// Contexts in their steady state (a fit before, nothing pending, accumulators known clean -- so that a pipeline is exactly: the
+// homography kernel, the pose kernel, the solve's trial launches) whose solve needs at most one workgroup per compute unit do not
+// get launches of their own: their enqueueing half runs with a recorder installed (ccal_kernels.hpp), and the records of all of
+// them are merged position by position into ONE launch per kernel instantiation, whose workgroups look their own fit's arguments
+// up in a device table.  Eight launches then carry 32 six-image fits instead of 256, and the chip runs them side by side; the
+// host-side bookkeeping, the per-context progress words and results are exactly those of ccal_fit.
+static bool merge_ok(const ccal_ctx *c) {
+    if (!c || !c->use_merge || c->time_sweeps || sharded(c) || c->p2p_split || !focal_exact(c) || c->init_hmode == 0 || !c->planar_z0 ||
+        (c->flags & CCAL_USE_INTRINSIC_GUESS) != 0 || c->foc_dirty || c->focal_pending || c->acc_dirty || !c->have_problem || !c->have_img ||
+        c->host_poses != nullptr)
+        return false;
+    if ((size_t)32 * c->P + sizeof(double) * 2200 > 60 * 1024) return false;               // (the pose kernel's staged-correspondence form)
+    // (a fit of more workgroups fills half the chip alone: merged with others every launch boundary waits for the slowest of them, and
+    //  streams of their own overlap better -- 1000 x 54 measured 67 us per fit on streams against 96 merged, six at a time)
+    return ((long)c->N * c->wpi + 3) / 4 <= 128;
+}
+
+struct MergeArena {
+    int device = -1;
+    char *d = nullptr, *h = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+};
+static thread_local MergeArena t_arena;
+
+static int arena_need(MergeArena &A, int device, size_t bytes) {
+    if (A.device == device && bytes <= A.cap) return CCAL_OK;
+    if (A.d) { (void)hipSetDevice(A.device); (void)hipDeviceSynchronize(); (void)hipFree(A.d); (void)hipHostFree(A.h); A.d = A.h = nullptr; A.cap = 0; }
+    HIPCHK(hipSetDevice(device));
+    if (!A.ev || A.device != device) {
+        if (A.ev) (void)hipEventDestroy(A.ev);
+        HIPCHK(hipEventCreateWithFlags(&A.ev, hipEventDisableTiming));
+    }
+    const size_t cap = bytes + bytes / 2 + 65536;
+    HIPCHK(hipMalloc(&A.d, cap));
+    HIPCHK(hipHostMalloc(&A.h, cap, hipHostMallocDefault));
+    A.cap = cap;
+    A.device = device;
+    return CCAL_OK;
+}
+
+static void merge_poison(ccal_ctx *c) {           // a recording was abandoned: nothing its bookkeeping says has happened
+    c->have_H = c->have_intr = c->have_ext = c->have_result = false;
+    c->focal_pending = false;
+    c->foc_dirty = true;
+    c->acc_dirty = true;
+}
+
+// the enqueueing half of every context in `idx` (same device, all merge_ok) as merged launches on the first one's stream.
+// false: nothing was launched and every context of `idx` is back in a state the ordinary fit_begin handles.
+static bool fit_begin_merged(ccal_ctx *const *ctxs, const std::vector<int> &idx, std::vector<FitPhase> &ph) {
+    const int m = (int)idx.size();
+    std::vector<MergeRecorder> rec((size_t)m);
+    bool ok = true;
+    static const bool dbg = getenv("CCAL_DEBUG_TIMING") != nullptr;
+    const double t_rec0 = now_s();
+    for (int e = 0; e < m; e++) {
+        ccal_ctx *c = ctxs[idx[e]];
+        merge_recorder() = &rec[e];
+        c->recording = true;
+        fit_begin(c, ph[idx[e]]);
+        c->recording = false;
+        merge_recorder() = nullptr;
+        const FitPhase &p = ph[idx[e]];
+        if (rec[e].unsupported || p.rc < 0 || p.lm_rc < 0 || !p.lm_begun || rec[e].recs.size() < 3 || rec[e].recs[0].kernel != MERGE_HOMOGRAPHY ||
+            rec[e].recs[1].kernel != MERGE_EXTRINSICS || rec[e].recs[2].kernel != MERGE_LM)
+            ok = false;
+    }
+    const double t_rec1 = now_s();
+    size_t len = 0;
+    for (int e = 0; e < m && ok; e++) {
+        len = std::max(len, rec[e].recs.size());
+        for (size_t j = 2; j < rec[e].recs.size(); j++) ok = ok && rec[e].recs[j].kernel == MERGE_LM;
+    }
+    ccal_ctx *c0 = ctxs[idx[0]];
+    MergeArena &A = t_arena;
+    // layout: three tables (entry = context), then per launch: map [grid] | first [m] | nblk [m]
+    struct Launch { int kernel, key, grid, k, first, final_only; size_t pos, dyn, off_map, off_first, off_nblk; std::vector<int> who; };
+    std::vector<Launch> launches;
+    size_t off_tab[3] = {0, 0, 0}, bytes = 0;
+    if (ok) {
+        for (int t = 0; t < 3; t++) { off_tab[t] = bytes; bytes += ((rec[0].recs[t].args_bytes * (size_t)m + 255) / 256) * 256; }
+        for (size_t j = 0; j < len; j++) {
+            for (int e = 0; e < m; e++) {
+                if (j >= rec[e].recs.size()) continue;
+                const MergeRecord &r = rec[e].recs[j];
+                Launch *L = nullptr;
+                for (auto &q : launches)
+                    if (q.pos == j && q.kernel == r.kernel && q.key == r.key && q.k == r.k && q.first == r.first && q.final_only == r.final_only) { L = &q; break; }
+                if (!L) {
+                    launches.push_back(Launch{r.kernel, r.key, 0, r.k, r.first, r.final_only, j, 0, 0, 0, 0, {}});
+                    L = &launches.back();
+                }
+                L->who.push_back(e);
+                L->grid += r.grid;
+                L->dyn = std::max(L->dyn, r.dyn_lds);
+            }
+        }
+        for (auto &L : launches) {
+            L.off_map = bytes; bytes += (((size_t)L.grid * 4 + 255) / 256) * 256;
+            L.off_first = bytes; bytes += (((size_t)m * 4 + 255) / 256) * 256;
+            L.off_nblk = bytes; bytes += (((size_t)m * 4 + 255) / 256) * 256;
+        }
+        ok = arena_need(A, c0->device, bytes) == CCAL_OK;
+    }
+    if (ok) {
+        for (int t = 0; t < 3; t++)
+            for (int e = 0; e < m; e++) memcpy(A.h + off_tab[t] + rec[e].recs[t].args_bytes * (size_t)e, rec[e].recs[t].args, rec[e].recs[t].args_bytes);
+        for (auto &L : launches) {
+            int *map = reinterpret_cast<int *>(A.h + L.off_map), *first = reinterpret_cast<int *>(A.h + L.off_first),
+                *nblk = reinterpret_cast<int *>(A.h + L.off_nblk);
+            for (int e = 0; e < m; e++) first[e] = nblk[e] = 0;
+            int b = 0;
+            for (int e : L.who) {
+                const int g = rec[e].recs[L.pos].grid;
+                first[e] = b; nblk[e] = g;
+                for (int q = 0; q < g; q++) map[b + q] = e;
+                b += g;
+            }
+        }
+        ok = hipSetDevice(c0->device) == hipSuccess && (A.ev == nullptr || hipEventSynchronize(A.ev) == hipSuccess) &&
+             hipMemcpyAsync(A.d, A.h, bytes, hipMemcpyHostToDevice, c0->stream) == hipSuccess;
+        // (from here on launches are in flight: a failure is a HIP error and fails the contexts, it cannot fall back)
+        if (ok) {
+            hipError_t he = hipSuccess;
+            for (auto &L : launches) {
+                const int *map = reinterpret_cast<const int *>(A.d + L.off_map), *first = reinterpret_cast<const int *>(A.d + L.off_first),
+                          *nblk = reinterpret_cast<const int *>(A.d + L.off_nblk);
+                if (L.kernel == MERGE_HOMOGRAPHY) he = launch_init_homography_multi(c0->stream, L.key, A.d + off_tab[0], map, first, L.grid);
+                else if (L.kernel == MERGE_EXTRINSICS) he = launch_init_extrinsics_multi(c0->stream, L.key, A.d + off_tab[1], map, first, L.grid, L.dyn);
+                else he = launch_lm_trial_multi(c0->stream, L.key, A.d + off_tab[2], map, first, nblk, L.grid, L.k, L.first, L.final_only);
+                if (he != hipSuccess) break;
+            }
+            if (dbg) fprintf(stderr, "[ccal] fit_many merged: %d contexts, %zu launches, %zu table bytes; recording %.1f us, merge + launches %.1f us\n", m,
+                             launches.size(), bytes, 1e6 * (t_rec1 - t_rec0), 1e6 * (now_s() - t_rec1));
+            if (he == hipSuccess) he = hipEventRecord(A.ev, c0->stream);
+            for (int e = 1; e < m && he == hipSuccess; e++)
+                if (ctxs[idx[e]]->stream != c0->stream) he = hipStreamWaitEvent(ctxs[idx[e]]->stream, A.ev, 0);
+            if (he != hipSuccess) {
+                (void)hipStreamSynchronize(c0->stream);
+                for (int e = 0; e < m; e++) {
+                    merge_poison(ctxs[idx[e]]);
+                    ph[idx[e]] = FitPhase();
+                    ph[idx[e]].rc = fail(CCAL_E_DEVICE, std::string("ccal_fit_many: merged launch failed: ") + hipGetErrorString(he));
+                    ph[idx[e]].err = g_err;
+                }
+            }
+            return true;
+        }
+    }
+    for (int e = 0; e < m; e++) merge_poison(ctxs[idx[e]]);     // nothing was launched: the ordinary path starts every one of them afresh
+    return false;
+}
+
 int ccal_fit_many(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out) {
     if (n < 0 || (n > 0 && !ctxs)) return fail(CCAL_E_ARG, "ccal_fit_many: bad arguments");
     for (int a = 0; a < n; a++)
@@ -1358,7 +1518,18 @@ int ccal_fit_many(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out) {
     // (enqueued by this one thread: helper threads enqueueing beside it were measured -- 2 and 4 threads, 32 contexts -- and changed
     //  nothing: the runtime serialises launch calls.  A pipeline costs the host ~14 us of launch calls, which is what bounds a batch
     //  of small fits: tools/many_timing.py)
-    for (int a = 0; a < n; a++) fit_begin(ctxs[a], ph[a]);
+    // steady-state contexts of one device: merged launches; the others: their own pipelines on their own streams
+    std::vector<char> merged((size_t)n, 0);
+    for (int dev = 0; dev < 16 && n > 1; dev++) {
+        std::vector<int> idx;
+        for (int a = 0; a < n; a++)
+            if (ctxs[a] && ctxs[a]->device == dev && merge_ok(ctxs[a])) idx.push_back(a);
+        if (idx.size() < 4) continue;                 // (two or three: their own streams are as fast -- tools/many_timing.py)
+        if (fit_begin_merged(ctxs, idx, ph))
+            for (int a : idx) merged[a] = 1;
+    }
+    for (int a = 0; a < n; a++)
+        if (!merged[a]) fit_begin(ctxs[a], ph[a]);
     static const bool dbg = getenv("CCAL_DEBUG_TIMING") != nullptr;
     static double dbg_enq = 0.0; static long dbg_calls = 0, dbg_n = 0;
     if (dbg) {
@@ -1367,12 +1538,14 @@ int ccal_fit_many(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out) {
     }
     int worst = CCAL_OK;
     std::string worst_err;
+    const double t_end0 = now_s();
     for (int a = 0; a < n; a++) {
         const int rc = fit_end(ctxs[a], ph[a]);
         if (status_out) status_out[a] = rc;
         if (rc < 0 && worst >= 0) { worst = rc; worst_err = "context " + std::to_string(a) + ": " + g_err; }
         else if (rc > worst && worst >= 0) worst = rc;
     }
+    if (dbg && dbg_calls % 20 == 0) fprintf(stderr, "[ccal] fit_many: waits + checks %.1f us for %d contexts\n", 1e6 * (now_s() - t_end0), n);
     if (worst < 0) g_err = worst_err;
     return worst;
 }

@@ -602,13 +602,15 @@ __device__ __forceinline__ void foc_acc_add(long long *__restrict__ rep, int col
 // ---------------------------------------------------------------------------------------
 // H_out [N][2][9]: the polished homography (what the focal-length least squares uses) and, behind it, the DLT's result before
 // the polish (what k_init_extrinsics starts OpenCV's second polish from, HMODE 1)
+// (the kernel's body, image i: shared by the ordinary launch -- image = workgroup -- and the merged launch of several fits)
 template <bool SPEC>
-__global__ __launch_bounds__(64) void k_init_homography(const float *__restrict__ obj, const float *__restrict__ img,
-                                                         double *__restrict__ H_out, double *__restrict__ foc,
-                                                         long long *__restrict__ foc_acc, int *__restrict__ fail0, int N,
-                                                         int P, int width, int height) {
+__device__ __forceinline__ void init_homography_body(const float *__restrict__ obj, const float *__restrict__ img,
+                                                     double *__restrict__ H_out, double *__restrict__ foc,
+                                                     long long *__restrict__ foc_acc, int *__restrict__ fail0, int N,
+                                                     int P, int width, int height, const int i) {
     __shared__ __attribute__((aligned(16))) double s_sums[sums_scratch_doubles(HSUMS)];
-    const int i = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
+    (void)N;
     if (fail0 != nullptr && i == 0 && lane == 0) *fail0 = 0;     // (pipeline form: no focal kernel will zero the pose stage's failure counter)
     const RawPoints raw{obj, reinterpret_cast<const float2 *>(img) + (size_t)i * P};
     CachedPoints<RawPoints> pts;
@@ -654,6 +656,30 @@ __global__ __launch_bounds__(64) void k_init_homography(const float *__restrict_
         // this GPU holds every image: the sums are formed right here, exactly (see foc_acc_add)
         if (foc_acc != nullptr && lane < NFOC - 2) foc_acc_add(foc_acc + (i & (FOC_REPL - 1)) * FOC_WORDS, lane, v);
     }
+}
+
+template <bool SPEC>
+__global__ __launch_bounds__(64) void k_init_homography(const float *__restrict__ obj, const float *__restrict__ img,
+                                                         double *__restrict__ H_out, double *__restrict__ foc,
+                                                         long long *__restrict__ foc_acc, int *__restrict__ fail0, int N,
+                                                         int P, int width, int height) {
+    init_homography_body<SPEC>(obj, img, H_out, foc, foc_acc, fail0, N, P, width, height, (int)blockIdx.x);
+}
+
+// merged launch (ccal_fit_many): the images of several independent fits in one grid; workgroup -> fit -> that fit's arguments
+struct HomArgs {
+    const float *obj, *img;
+    double *H_out, *foc;
+    long long *foc_acc;
+    int *fail0;
+    int N, P, width, height;
+};
+template <bool SPEC>
+__global__ __launch_bounds__(64) void k_init_homography_multi(const HomArgs *__restrict__ table, const int *__restrict__ map,
+                                                               const int *__restrict__ first) {
+    const int fit = map[blockIdx.x];
+    const HomArgs a = table[fit];
+    init_homography_body<SPEC>(a.obj, a.img, a.H_out, a.foc, a.foc_acc, a.fail0, a.N, a.P, a.width, a.height, (int)blockIdx.x - first[fit]);
 }
 
 // [OCV-K cvInitIntrinsicParams2D]: cvSolve(A, b, f, CV_NORMAL + CV_SVD) on the 2x2 normal equations (one thread)
@@ -920,12 +946,13 @@ struct FocalArgs {
     double aspect;
 };
 template <bool SPEC, int HMODE, bool LDSP, bool FOC = false>
-__global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const float *__restrict__ obj, const float *__restrict__ img,
-                                                         const double *__restrict__ intr0, const double *__restrict__ H_pix,
-                                                         double *__restrict__ ext,
-                                                         int *__restrict__ fail_count, int N, int P, const FocalArgs F) {
+__device__ __forceinline__ void init_extrinsics_body(const float *__restrict__ obj, const float *__restrict__ img,
+                                                     const double *__restrict__ intr0, const double *__restrict__ H_pix,
+                                                     double *__restrict__ ext,
+                                                     int *__restrict__ fail_count, int N, int P, const FocalArgs &F, const int i) {
     __shared__ __attribute__((aligned(16))) double s_sums[sums_scratch_doubles(HSUMS)];
-    const int i = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
+    (void)N;
     const float2 *img_i = reinterpret_cast<const float2 *>(img) + (size_t)i * P;
 
     NormPoints pts;
@@ -1216,9 +1243,67 @@ __global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const floa
     }
 }
 
+template <bool SPEC, int HMODE, bool LDSP, bool FOC = false>
+__global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics(const float *__restrict__ obj, const float *__restrict__ img,
+                                                         const double *__restrict__ intr0, const double *__restrict__ H_pix,
+                                                         double *__restrict__ ext,
+                                                         int *__restrict__ fail_count, int N, int P, const FocalArgs F) {
+    init_extrinsics_body<SPEC, HMODE, LDSP, FOC>(obj, img, intr0, H_pix, ext, fail_count, N, P, F, (int)blockIdx.x);
+}
+
+struct ExtArgs {
+    const float *obj, *img;
+    const double *intr0, *H_pix;
+    double *ext;
+    int *fail_count;
+    int N, P;
+    FocalArgs F;
+};
+template <bool SPEC, int HMODE, bool LDSP, bool FOC>
+__global__ __launch_bounds__(64, SPEC ? 1 : 2) void k_init_extrinsics_multi(const ExtArgs *__restrict__ table, const int *__restrict__ map,
+                                                                             const int *__restrict__ first) {
+    const int fit = map[blockIdx.x];
+    const ExtArgs a = table[fit];
+    init_extrinsics_body<SPEC, HMODE, LDSP, FOC>(a.obj, a.img, a.intr0, a.H_pix, a.ext, a.fail_count, a.N, a.P, a.F, (int)blockIdx.x - first[fit]);
+}
+
 // ---------------------------------------------------------------------------------------
+static_assert(sizeof(HomArgs) <= sizeof(MergeRecord::args) && sizeof(ExtArgs) <= sizeof(MergeRecord::args), "a recorded launch keeps its arguments by value");
+template <class Args>
+static void merge_add(MergeRecorder *r, int kernel, int key, int grid, size_t dyn, const Args &a) {
+    MergeRecord m;
+    m.kernel = kernel; m.key = key; m.grid = grid; m.block = 64; m.dyn_lds = dyn;
+    memcpy(m.args, &a, sizeof a);
+    m.args_bytes = sizeof a;
+    r->recs.push_back(m);
+}
+
+// key = SPEC
+hipError_t launch_init_homography_multi(hipStream_t stream, int key, const void *table, const int *map, const int *first, int grid) {
+    const HomArgs *t = static_cast<const HomArgs *>(table);
+    if (key & 1) hipLaunchKernelGGL(k_init_homography_multi<true>, dim3(grid), dim3(64), 0, stream, t, map, first);
+    else hipLaunchKernelGGL(k_init_homography_multi<false>, dim3(grid), dim3(64), 0, stream, t, map, first);
+    return hipGetLastError();
+}
+// key = SPEC | HMODE << 1 (pipeline form with the staged correspondences only: FOC, LDSP)
+hipError_t launch_init_extrinsics_multi(hipStream_t stream, int key, const void *table, const int *map, const int *first, int grid, size_t dyn_lds) {
+    const ExtArgs *t = static_cast<const ExtArgs *>(table);
+    const int spec = key & 1, hmode = key >> 1;
+    if (hmode == 2 && spec) hipLaunchKernelGGL((k_init_extrinsics_multi<true, 2, true, true>), dim3(grid), dim3(64), dyn_lds, stream, t, map, first);
+    else if (hmode == 2) hipLaunchKernelGGL((k_init_extrinsics_multi<false, 2, true, true>), dim3(grid), dim3(64), dyn_lds, stream, t, map, first);
+    else if (hmode == 1 && spec) hipLaunchKernelGGL((k_init_extrinsics_multi<true, 1, true, true>), dim3(grid), dim3(64), dyn_lds, stream, t, map, first);
+    else if (hmode == 1) hipLaunchKernelGGL((k_init_extrinsics_multi<false, 1, true, true>), dim3(grid), dim3(64), dyn_lds, stream, t, map, first);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 hipError_t launch_init_homography(hipStream_t stream, const float *obj, const float *img, double *H_out,
                                   double *foc_partials, long long *foc_acc, int *fail0, int N, int P, int width, int height, bool spec) {
+    if (MergeRecorder *r = merge_recorder()) {
+        const HomArgs a{obj, img, H_out, foc_partials, foc_acc, fail0, N, P, width, height};
+        merge_add(r, MERGE_HOMOGRAPHY, spec ? 1 : 0, N, 0, a);
+        return hipSuccess;
+    }
     // up to one image per SIMD the launch is as long as its slowest image: trial points by the normal-equations pass;
     // beyond that it is throughput: the leaner form that keeps two waves per SIMD
     if (spec)
@@ -1281,6 +1366,12 @@ hipError_t launch_init_extrinsics(hipStream_t stream, const float *obj, const fl
         if (hmode == 0) return hipErrorInvalidValue;      // (the pipeline form needs the intrinsics stage's homographies)
         F.acc = focal->acc; F.acc_clear = focal->acc_clear; F.intr0_out = focal->intr0_out;
         F.width = focal->width; F.height = focal->height; F.aspect = focal->aspect;
+    }
+    if (MergeRecorder *r = merge_recorder()) {
+        if (!foc || !ldsp) { r->unsupported = true; return hipErrorInvalidValue; }   // (merged form: the pipeline with staged correspondences)
+        const ExtArgs a{obj, img, intr0, H_pix, ext, fail_count, N, P, F};
+        merge_add(r, MERGE_EXTRINSICS, (spec ? 1 : 0) | hmode << 1, N, hmode == 2 ? 0 : lds_pts, a);
+        return hipSuccess;
     }
     auto go = [&](auto kernel, size_t dyn) {
         hipLaunchKernelGGL(kernel, dim3(N), dim3(64), dyn, stream, obj, img, intr0, H_pix, ext, fail_count, N, P, F);

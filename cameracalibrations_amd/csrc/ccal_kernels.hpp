@@ -3,6 +3,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "ccal_p2p.hpp"
 #include "ccal_state.hpp"
 
@@ -11,6 +13,32 @@ namespace ccal {
 // ccal_lm.hip
 int lm_sweep_blocks(int N);
 int lm_waves_per_image(int N, int P, bool fused);   // 1, 2 or 4: multi-pass boards are split over the waves of a workgroup while that fits the chip
+// ---- merged launches (ccal_fit_many): the workgroups of several independent fits in one grid ------------------------------------
+// While a recorder is installed on the calling thread, the three launch functions of a steady-state pipeline
+// (launch_init_homography, launch_init_extrinsics, launch_lm_trial) append what they would have launched instead of launching it.
+// The caller then merges the records of several contexts position by position: one launch_*_multi per kernel instantiation,
+// whose workgroups find their own fit's arguments in a device table (args as recorded, one entry per fit).
+enum { MERGE_HOMOGRAPHY = 0, MERGE_EXTRINSICS = 1, MERGE_LM = 2 };
+struct MergeRecord {
+    int kernel = 0;               // MERGE_*
+    int key = 0;                  // which instantiation (the launch function's own encoding)
+    int grid = 0, block = 0;
+    size_t dyn_lds = 0;
+    int k = 0, first = 0, final_only = 0;     // MERGE_LM: the per-launch words (everything else is the same for every trial of a solve)
+    unsigned char args[512];
+    size_t args_bytes = 0;
+};
+struct MergeRecorder {
+    std::vector<MergeRecord> recs;
+    bool unsupported = false;     // a launch that has no merged form was attempted: the caller discards the recording
+};
+MergeRecorder *&merge_recorder();          // this thread's recorder (nullptr: launches launch)
+// table: device array of the recorded args (entry = fit), map [grid] fit of each workgroup, first / nblk [fits] (device)
+hipError_t launch_lm_trial_multi(hipStream_t stream, int key, const void *table, const int *map, const int *first, const int *nblk, int grid,
+                                 int k, int is_first, int final_only);
+hipError_t launch_init_homography_multi(hipStream_t stream, int key, const void *table, const int *map, const int *first, int grid);
+hipError_t launch_init_extrinsics_multi(hipStream_t stream, int key, const void *table, const int *map, const int *first, int grid, size_t dyn_lds);
+
 int lm_solo_max_images();        // fits of at most this many images on one GPU run all their trials in ONE launch (TrialLaunch::solo)
 int lm_sweep_form(int N, int wpi, bool xchg, bool solo);   // ccal_stats.sweep_form of such a sweep
 int lm_max_grid();               // workgroups of k_lm_trial resident on the current device (the sweep grid is capped there)

@@ -507,6 +507,12 @@ struct TrialArgs {
     double *host_init_intr;       // ... and the start intrinsics go to pinned host memory (a pipelined fit needs no read-back kernel)
     int *host_init_fail;
     P2PDev p2p;                   // used by the exchanging instantiations only
+    // MULTI launches (the workgroups of several independent fits in one grid: ccal_fit_many) -- the by-value argument carries only
+    // these and k / first / final_only; everything else of a workgroup's fit comes from multi_table[multi_map[blockIdx.x]]
+    const TrialArgs *multi_table;
+    const int *multi_map;         // [grid]: which fit a workgroup belongs to
+    const int *multi_first;       // [fits]: the fit's first workgroup in this grid
+    const int *multi_nblk;        // [fits]: its number of workgroups
 };
 static_assert(offsetof(TrialArgs, R) + sizeof(int) == 64, "the launch's first loads take their addresses from the first 64 bytes");
 
@@ -579,12 +585,25 @@ enum : int { FLOW_PRO = 0, FLOW_PRO_XCHG = 1 };
 #define CCAL_SOLO_WAVES 4
 #endif
 constexpr int SOLO_WAVES = CCAL_SOLO_WAVES;
-template <int FLOW, bool LOOP, int KIND, int WPI = 1, bool SOLO = false>
+template <int FLOW, bool LOOP, int KIND, int WPI = 1, bool SOLO = false, bool MULTI = false>
 #ifndef CCAL_SOLO_MINW
 #define CCAL_SOLO_MINW 1
 #endif
-__global__ __launch_bounds__((SOLO ? SOLO_WAVES : WAVES) * 64, SOLO ? CCAL_SOLO_MINW : CCAL_TRIAL_MIN_WAVES) void k_lm_trial(const TrialArgs A) {
+__global__ __launch_bounds__((SOLO ? SOLO_WAVES : WAVES) * 64, SOLO ? CCAL_SOLO_MINW : CCAL_TRIAL_MIN_WAVES) void k_lm_trial(const TrialArgs A_in) {
     constexpr bool XCHG = FLOW == FLOW_PRO_XCHG;
+    static_assert(!MULTI || (FLOW == FLOW_PRO && !LOOP), "merged launches: single-GPU fits, one image group per workgroup");
+    // MULTI: this workgroup's fit, its index among that fit's workgroups and their number (otherwise: the grid's)
+    TrialArgs A_own;
+    int bid = (int)blockIdx.x, nblk = (int)gridDim.x;
+    if constexpr (MULTI) {
+        const int fit = A_in.multi_map[blockIdx.x];
+        A_own = A_in.multi_table[fit];
+        A_own.k = A_in.k; A_own.first = A_in.first; A_own.final_only = A_in.final_only;
+        bid = (int)blockIdx.x - A_in.multi_first[fit];
+        nblk = A_in.multi_nblk[fit];
+    }
+    const TrialArgs &A = MULTI ? A_own : A_in;
+    (void)nblk;
     static_assert(!SOLO || (FLOW == FLOW_PRO && !LOOP && KIND == 1 && WPI == 1), "one-launch solves: single GPU, one image per wave");
     constexpr int NW = SOLO ? SOLO_WAVES : WAVES;   // waves of the workgroup
     static_assert(WPI == 1 || WPI == 2 || WPI == 4, "waves per image");
@@ -638,7 +657,7 @@ __global__ __launch_bounds__((SOLO ? SOLO_WAVES : WAVES) * 64, SOLO ? CCAL_SOLO_
     // wave): the grid is capped at what the chip holds resident, so that the prologue above the loop -- state,
     // accumulators, LM advance -- runs once per resident workgroup, not once per four images.
     const int n_groups = (N + IPW - 1) / IPW;
-    int g = blockIdx.x;
+    int g = bid;
     const int sub = WPI == 1 ? 0 : (wave & (WPI - 1));   // which share of the image's corners this wave takes
     const bool leader = sub == 0;               // the wave that factors the image and writes its block
     int img_i = g * IPW + (WPI == 1 ? wave : wave / WPI);
@@ -691,7 +710,7 @@ __global__ __launch_bounds__((SOLO ? SOLO_WAVES : WAVES) * 64, SOLO ? CCAL_SOLO_
         uv = img2[pc0];                         // coalesced 8 B per lane
         m0 = A.obj[3 * pc0]; m1 = A.obj[3 * pc0 + 1]; m2 = A.obj[3 * pc0 + 2];
         // the buffer the NEXT trial adds into was last read one launch ago: clear it now (SOLO: no accumulators in use)
-        if (!SOLO && blockIdx.x == 0) acc_clear(A.acc + (size_t)((kk + 1) % 3) * acc_buf, A.R, 1, tid);
+        if (!SOLO && bid == 0) acc_clear(A.acc + (size_t)((kk + 1) % 3) * acc_buf, A.R, 1, tid);
     }
     int oa, ob;                                 // (a, b) of the packed S0 entry this lane assembles
     tri_decode(lane < 45 ? lane : 0, oa, ob);
@@ -712,7 +731,7 @@ __global__ __launch_bounds__((SOLO ? SOLO_WAVES : WAVES) * 64, SOLO ? CCAL_SOLO_
     unsigned int seq = 0;
     if constexpr (XCHG) seq = __hip_atomic_load(A.p2p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (first) {
-        if (blockIdx.x == 0 && A.host_init_intr != nullptr && tid < NINTR + 4) {
+        if (bid == 0 && A.host_init_intr != nullptr && tid < NINTR + 4) {
             // what the initialisation stages left for the host: nine start intrinsics, four failure words (ccal_fit reads them
             // after the solve; they used to travel by a kernel of their own between the pose stage and this launch).  Only when
             // a pose stage has run since the last report (its kernel raises word 2): stores to host memory hold the launch's
@@ -728,7 +747,7 @@ __global__ __launch_bounds__((SOLO ? SOLO_WAVES : WAVES) * 64, SOLO ? CCAL_SOLO_
         lm_boot(&ls, A.init, A.intr0, tid);
         // no other workgroup of this launch reads the sequence number; the launches after it see seq + 1
         if constexpr (XCHG)
-            if (blockIdx.x == 0 && tid == 0)
+            if (bid == 0 && tid == 0)
                 __hip_atomic_store(A.p2p.epoch, seq + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else if constexpr (SOLO) {
         // the sums of trial k - 1 are in s_rs / s_S (end of the previous pass), the state has stayed in LDS
@@ -748,7 +767,7 @@ __global__ __launch_bounds__((SOLO ? SOLO_WAVES : WAVES) * 64, SOLO ? CCAL_SOLO_
             // solve already terminated: surplus launch.  The terminal state is carried along, so every
             // later launch of the batch sees it too (none of them sweeps or exchanges again); the
             // terminating launch leaves all accumulators cleared for the next solve.
-            if (blockIdx.x == 0) {
+            if (bid == 0) {
                 LmState *cur = A.st + (kk & 1);
                 if (tid < STATE_WORDS) reinterpret_cast<double *>(cur)[tid] = reinterpret_cast<const double *>(&ls)[tid];
                 if ((KIND == 2)) acc_clear(A.acc, A.R, ACC_BUFS, tid);
@@ -766,7 +785,7 @@ __global__ __launch_bounds__((SOLO ? SOLO_WAVES : WAVES) * 64, SOLO ? CCAL_SOLO_
         if constexpr (XCHG)
             if (A.xchg_fused) {
                 p2p_exchange_rows(A.p2p, p2p_tag(seq, (unsigned)kk), p2p_slot(seq, (unsigned)kk), s_rs, s_all, NRED, tid,
-                                  blockIdx.x == 0);
+                                  bid == 0);
                 if (tid < RED_DA) {               // the symmetric copy again, now of the sum over the ranks (wave 0 only)
                     const double v = s_rs[tid];
                     s_S[oa * SROW + ob] = v;
@@ -777,7 +796,7 @@ __global__ __launch_bounds__((SOLO ? SOLO_WAVES : WAVES) * 64, SOLO ? CCAL_SOLO_
         STAMP(12);
         if (wave == 0) {
             if ((KIND == 2)) lm_advance_wave<true, true>(&ls, s_rs, s_S, A.trace, lane, kk);     // (one workgroup: it keeps the books)
-            else if (blockIdx.x == 0) lm_advance_wave<true, false>(&ls, s_rs, s_S, A.trace, lane, kk);
+            else if (bid == 0) lm_advance_wave<true, false>(&ls, s_rs, s_S, A.trace, lane, kk);
             else lm_advance_wave<false, false>(&ls, s_rs, s_S, nullptr, lane, kk);
         }
         __syncthreads();
@@ -785,7 +804,7 @@ __global__ __launch_bounds__((SOLO ? SOLO_WAVES : WAVES) * 64, SOLO ? CCAL_SOLO_
     STAMP(1);
     WG_TIME(1);
     const bool budget_out = SOLO && kk >= A.max_trials;   // the launch ends here even if the solve has not (the host reports it)
-    if (blockIdx.x == 0 && (!SOLO || ls.done || budget_out)) {
+    if (bid == 0 && (!SOLO || ls.done || budget_out)) {
         LmState *cur = A.st + (kk & 1);
         if (tid < STATE_WORDS) reinterpret_cast<double *>(cur)[tid] = reinterpret_cast<const double *>(&ls)[tid];
         if (ls.done && A.host_poses != nullptr) {
@@ -844,7 +863,7 @@ __global__ __launch_bounds__((SOLO ? SOLO_WAVES : WAVES) * 64, SOLO ? CCAL_SOLO_
     };
 
     for (bool first_group = true;; first_group = false) {
-    const int g_next = g + (int)gridDim.x;
+    const int g_next = g + nblk;
     const bool last_group = !LOOP || g_next >= n_groups;   // workgroup-uniform
     // ---- 2. block head of the accepted point -> wave-uniform registers ----
     // lane j holds block word j (hsel) and word 64 + j (hselb); uniform values are pulled out with
@@ -1062,7 +1081,7 @@ __global__ __launch_bounds__((SOLO ? SOLO_WAVES : WAVES) * 64, SOLO ? CCAL_SOLO_
         // ... and exact, order-independent across workgroups: limbs added with integer atomics
         // (replica = workgroup index mod R: with R = 8 and round-robin dispatch that is the workgroup's XCD, so one
         //  replica is only ever added to through one L2 -- choosing it from HW_REG_XCC_ID instead measured the same)
-        acc_add(A.acc + ((size_t)(kk % 3) * A.R + (blockIdx.x & (A.R - 1))) * ACC_ROW, tid, s);
+        acc_add(A.acc + ((size_t)(kk % 3) * A.R + (bid & (A.R - 1))) * ACC_ROW, tid, s);
     }
     }
     STAMP(9);
@@ -1320,6 +1339,42 @@ int lm_max_grid() {
     return cached[dev] = std::min(per_cu * cus, LM_GRID_LIMIT);
 }
 
+MergeRecorder *&merge_recorder() {
+    static thread_local MergeRecorder *r = nullptr;
+    return r;
+}
+static_assert(sizeof(TrialArgs) <= sizeof(MergeRecord::args), "a recorded launch keeps its arguments by value");
+
+static void merge_add(MergeRecorder *r, int kernel, int key, int grid, int block, size_t dyn, const TrialArgs &a) {
+    MergeRecord m;
+    m.kernel = kernel; m.key = key; m.grid = grid; m.block = block; m.dyn_lds = dyn;
+    m.k = a.k; m.first = a.first; m.final_only = a.final_only;
+    memcpy(m.args, &a, sizeof a);
+    m.args_bytes = sizeof a;
+    r->recs.push_back(m);
+}
+
+// key = KIND | WPI << 4 | SOLO << 8
+hipError_t launch_lm_trial_multi(hipStream_t stream, int key, const void *table, const int *map, const int *first, const int *nblk, int grid,
+                                 int k, int is_first, int final_only) {
+    TrialArgs a;
+    memset(&a, 0, sizeof a);
+    a.multi_table = static_cast<const TrialArgs *>(table); a.multi_map = map; a.multi_first = first; a.multi_nblk = nblk;
+    a.k = k; a.first = is_first; a.final_only = final_only;
+    const int kind = key & 15, wpi = (key >> 4) & 15, solo = (key >> 8) & 1;
+    auto go = [&](auto kernel, int block) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, a); };
+    if (solo) go(k_lm_trial<FLOW_PRO, false, 1, 1, true, true>, SOLO_WAVES * 64);
+    else if (kind == 2) go(k_lm_trial<FLOW_PRO, false, 2, 1, false, true>, WAVES * 64);
+    else if (kind == 0 && wpi == 4) go(k_lm_trial<FLOW_PRO, false, 0, 4, false, true>, WAVES * 64);
+    else if (kind == 1 && wpi == 4) go(k_lm_trial<FLOW_PRO, false, 1, 4, false, true>, WAVES * 64);
+    else if (kind == 0 && wpi == 2) go(k_lm_trial<FLOW_PRO, false, 0, 2, false, true>, WAVES * 64);
+    else if (kind == 1 && wpi == 2) go(k_lm_trial<FLOW_PRO, false, 1, 2, false, true>, WAVES * 64);
+    else if (kind == 0 && wpi == 1) go(k_lm_trial<FLOW_PRO, false, 0, 1, false, true>, WAVES * 64);
+    else if (kind == 1 && wpi == 1) go(k_lm_trial<FLOW_PRO, false, 1, 1, false, true>, WAVES * 64);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     if (t.acc == nullptr || t.R < 1 || t.R > ACC_MAX_REPLICAS || (t.R & (t.R - 1)) != 0) return hipErrorInvalidValue;
     TrialArgs a;
@@ -1333,9 +1388,16 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     a.host_poses = t.host_poses;
     a.init_fail = t.init_fail; a.host_init_intr = t.host_init_intr; a.host_init_fail = t.host_init_fail;
     memset(&a.p2p, 0, sizeof a.p2p);
+    a.multi_table = nullptr; a.multi_map = nullptr; a.multi_first = nullptr; a.multi_nblk = nullptr;
+    MergeRecorder *rec = merge_recorder();
+    if (rec != nullptr && (t.p2p != nullptr || t.row_in != nullptr || t.ev_start != nullptr || t.gram_out != nullptr)) {
+        rec->unsupported = true;
+        return hipErrorInvalidValue;
+    }
     if (t.solo) {
         // every trial of the solve in ONE launch of one workgroup (a few images on one GPU: no accumulators, no row, no exchange)
         if (t.N > SOLO_WAVES || t.final_only || t.row_in != nullptr || t.p2p != nullptr || t.k != 0 || t.max_trials < 1) return hipErrorInvalidValue;
+        if (rec != nullptr) { merge_add(rec, MERGE_LM, 1 | 1 << 4 | 1 << 8, 1, SOLO_WAVES * 64, 0, a); return hipSuccess; }
         if (t.ev_start != nullptr && t.ev_stop != nullptr)
             hipExtLaunchKernelGGL((k_lm_trial<FLOW_PRO, false, 1, 1, true>), dim3(1), dim3(SOLO_WAVES * 64), 0, stream, t.ev_start, t.ev_stop, 0, a);
         else
@@ -1347,6 +1409,11 @@ hipError_t launch_lm_trial(hipStream_t stream, const TrialLaunch &t) {
     const int groups = wpi == 1 ? lm_sweep_blocks(t.N) : (t.N * wpi + WAVES - 1) / WAVES;
     const int grid = t.final_only ? 1 : std::min(groups, lm_max_grid());
     const bool loop = !t.final_only && grid < groups;
+    if (rec != nullptr) {
+        if (loop) { rec->unsupported = true; return hipErrorInvalidValue; }
+        merge_add(rec, MERGE_LM, (t.final_only ? 2 : (t.first ? 0 : 1)) | wpi << 4, grid, WAVES * 64, 0, a);
+        return hipSuccess;
+    }
     auto launch = [&](auto kernel) {
         if (t.ev_start != nullptr && t.ev_stop != nullptr)   // events bound to this dispatch: its own begin / end
             hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(WAVES * 64), 0, stream, t.ev_start, t.ev_stop, 0, a);

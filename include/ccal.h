@@ -82,8 +82,9 @@ typedef struct ccal_stats {
     int32_t lambda_lg10;   /* final log10(lambda) */
     int32_t n_bad;         /* images whose 6x6 block was not positive definite in the last sweep */
     int32_t timed_sweeps;  /* sweeps covered by sweep_us (0 unless ccal_set_sweep_timing is on) */
-    int32_t sweep_form;    /* which instantiation k_lm_trial<FLOW, LOOP, KIND, WPI, SOLO> swept: FLOW | LOOP << 4 | WPI << 8 | SOLO << 12
-                            * (FLOW 1 = row exchange fused in, LOOP = looping grid, WPI = waves per image, SOLO = every trial in one launch) */
+    int32_t sweep_form;    /* which instantiation k_lm_trial<FLOW, LOOP, KIND, WPI, SOLO, MULTI> swept: FLOW | LOOP << 4 | WPI << 8 | SOLO << 12 |
+                            * MULTI << 16 (FLOW 1 = row exchange fused in, LOOP = looping grid, WPI = waves per image, SOLO = every trial in
+                            * one launch, MULTI = launches shared with other contexts' fits: ccal_fit_many) */
     double sweep_us;       /* mean device time of the sweep kernel, HIP events on the launch stream */
     double solve_kernels_us; /* device time of ALL launches of the solve (every trial + the terminating one), summed;
                               * 0 unless ccal_set_sweep_timing is on */
@@ -201,7 +202,10 @@ int  ccal_fit(ccal_ctx *ctx);
  * src/buildcalibrations.jl:12-26): every context's pipeline is enqueued on its own stream before any is waited for, so the
  * GPU overlaps them -- a fit of a few images occupies a few compute units and spends most of its time in launch and
  * hand-off latency.  Contexts may live on different devices; shards of a joint fit are refused (CCAL_E_STATE).  Each
- * context ends exactly as after its own ccal_fit (same bits; results through ccal_get_result).  status_out[i] (may be
+ * context ends exactly as after its own ccal_fit (same bits; results through ccal_get_result).  Four or more contexts of one
+ * device whose fits are small (at most 128 workgroups per sweep: up to 128 images of a one-pass board) and in their steady state
+ * (a fit before on the same context) do not even get launches of their own: their kernels are merged into one launch per
+ * pipeline stage whose workgroups look their own fit up in a table (ccal_stats.sweep_form bit 16; CCAL_NO_MERGE=1 disables).  status_out[i] (may be
  * NULL) = what ccal_fit would have returned for context i; the return value is the first failure, else the largest
  * warning; ccal_last_error() then names that context. */
 int  ccal_fit_many(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out);

@@ -1313,7 +1313,7 @@ def test_fit_many_equals_one_fit_at_a_time(golden_dir):
     call reuses the captured graphs, and fit_models returns what fit_model returns for each set of the reference's example."""
     from cameracalibrations_amd import _ffi as F, fit_many, fit_models
     specs = [("C1", 7, REF), ("C2", 40, REF), ("REF", 6, REF), ("C5", 5, REF), ("C2", 300, TIGHT), ("C1", 100, REF), ("C2", 3, REF),
-             ("C5", 40, REF), ("REF", 129, REF)]
+             ("C5", 40, REF), ("REF", 129, REF), ("C2", 600, REF)]
     wls = [syn.named_workload(n, n_images=k, seed_offset=i) for i, (n, k, _) in enumerate(specs)]
     alone = []
     for wl, (_, _, crit) in zip(wls, specs):
@@ -1324,9 +1324,14 @@ def test_fit_many_equals_one_fit_at_a_time(golden_dir):
     try:
         for rep in range(3):
             sts = fit_many(solvers)
-            for s, st, (st0, r0) in zip(solvers, sts, alone):
+            for i, (s, st, (st0, r0)) in enumerate(zip(solvers, sts, alone)):
                 r = s.result()
                 assert st == st0 and r["iters"] == r0["iters"] and r["sweeps"] == r0["sweeps"]
+                # from the second call on (contexts in their steady state) the small fits share merged launches: the workgroups of
+                # several contexts in one grid, each looking its own fit up in a table (sweep_form bit 16); 600 images stay on their own
+                small = specs[i][1] * (r["sweep_form"] >> 8 & 15) <= 512
+                assert (r["sweep_form"] >> 16) == (1 if rep > 0 and small else 0), (rep, i, hex(r["sweep_form"]))
+                assert (r["sweep_form"] & 0xFFFF) == (r0["sweep_form"] & 0xFFFF)
                 for k in ("intr", "rvecs", "tvecs"):
                     assert np.array_equal(r[k], r0[k]), k
                 assert r["rms"] == r0["rms"]

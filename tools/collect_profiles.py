@@ -14,7 +14,7 @@ P = os.path.join(ROOT, "profiles")
 
 
 def template_args(name):
-    """'void ccal::k_lm_trial<0, false, 1, 1, false>(ccal::TrialArgs)' -> ['0', 'false', '1', '1', 'false']"""
+    """'void ccal::k_lm_trial<0, false, 1, 1, false, false>(ccal::TrialArgs)' -> ['0', 'false', '1', '1', 'false', 'false']"""
     return [a.strip() for a in name.split("<", 1)[1].split(">", 1)[0].split(",")] if "<" in name else []
 
 
@@ -47,7 +47,7 @@ def trace_summary(path):
 runs = {"C3 1000x54 (bench.py --steps 50, as the driver runs it)": "c3", "C5 10000x150 on one GPU": "c5",
         "C5 per-GPU share at 8 GPUs (1250x150)": "c5shard"}
 summary = {"what": "rocprofv3 --kernel-trace of the commands in tools/profiles.sh: duration of ccal::k_lm_trial by instantiation "
-                   "<FLOW, LOOP, KIND, WPI, SOLO> (KIND 0 = first launch of a solve, 1 = later trial, 2 = terminating prologue-only launch); surplus early-return launches excluded",
+                   "<FLOW, LOOP, KIND, WPI, SOLO, MULTI> (KIND 0 = first launch of a solve, 1 = later trial, 2 = terminating prologue-only launch); surplus early-return launches excluded",
            "runs": {k: trace_summary(os.path.join(G, R + "_prof", d, "prof_kernel_trace.csv")) for k, d in runs.items()}}
 json.dump(summary, open(os.path.join(P, R + "_kernel_trace_summary.json"), "w"), indent=1)
 for src, dst in (("_prof/c3/prof_kernel_stats.csv", "_bench_kernel_stats.csv"), ("_prof/c5/prof_kernel_stats.csv", "_c5_kernel_stats.csv"),
