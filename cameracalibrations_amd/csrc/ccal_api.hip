@@ -222,10 +222,14 @@ int ccal_create(int device, ccal_ctx **out) {
     HIPCHK(hipMalloc(&c->d_st_scratch, sizeof(LmState) * 2));
     HIPCHK(hipMalloc(&c->d_red, sizeof(double) * NRED));
     HIPCHK(hipMalloc(&c->d_acc, ACC_BYTES));
+    HIPCHK(hipMemset(c->d_acc, 0, ACC_BYTES));                 // a new context starts in the steady state every solve leaves behind (accumulators
+    c->acc_dirty = false;                                      // all zero): its first fit needs no clears and can share merged launches
     HIPCHK(hipMalloc(&c->d_acc_scratch, ACC_BYTES));
     HIPCHK(hipMemset(c->d_acc_scratch, 0, ACC_BYTES));
     HIPCHK(hipMalloc(&c->d_foc_red, sizeof(double) * NFOC));
     HIPCHK(hipMalloc(&c->d_foc_acc, sizeof(long long) * 2 * LM_FOC_ACC_WORDS));
+    HIPCHK(hipMemset(c->d_foc_acc, 0, sizeof(long long) * 2 * LM_FOC_ACC_WORDS));
+    c->foc_dirty = false;
     HIPCHK(hipMalloc(&c->d_fail, sizeof(int) * 4));
     HIPCHK(hipMemset(c->d_fail, 0, sizeof(int) * 4));
     HIPCHK(hipMalloc(&c->d_intr0, sizeof(double) * 9));
