@@ -390,6 +390,23 @@ def many_block(contexts=32, rounds=25):
                              "images": int(img.shape[0]), "corners_per_image": int(img.shape[1])}
         for s in solvers:
             s.close()
+    # the same through the drop-in seam, host arrays in and out (PCIe and Python inclusive): fit_model per calibration | one fit_models
+    obj = cc.board_template(ex["n_corners"])
+    base = np.stack([np.array(m, dtype=np.float64).reshape(-1, 2) for m in ex["corners"]])
+    sets = [list(base + rng.normal(0, 0.05, base.shape)) for _ in range(contexts)]
+    t_seq, t_many = [], []
+    for rep in range(rounds + 3):
+        t0 = time.perf_counter()
+        for pts in sets:
+            cc.fit_model(ex["image_size_wh"], obj, pts, ex["n_corners"], True, 1)
+        t1 = time.perf_counter()
+        cc.fit_models(ex["image_size_wh"], obj, sets, ex["n_corners"], True, 1)
+        t2 = time.perf_counter()
+        t_seq.append((t1 - t0) / contexts)
+        t_many.append((t2 - t1) / contexts)
+    a, b = float(np.median(t_seq[3:])), float(np.median(t_many[3:]))
+    out["ref_example_drop_in"] = {"us_per_calibration_fit_model": 1e6 * a, "us_per_calibration_fit_models": 1e6 * b, "speedup": a / b,
+                                  "what": "host lists in / namespaces out: fit_model called per calibration | one fit_models(...) = ccal_calibrate_many"}
     return out
 
 

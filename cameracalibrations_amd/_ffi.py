@@ -86,6 +86,8 @@ SIGNATURES = {
     "ccal_lm_run": (C.c_int, [C.c_void_p]),
     "ccal_fit": (C.c_int, [C.c_void_p]),
     "ccal_fit_many": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int32)]),
+    "ccal_calibrate_many": (C.c_int, [_fp, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_double,
+                                      C.c_uint32, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     "ccal_set_sweep_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "ccal_set_graph": (C.c_int, [C.c_void_p, C.c_int32]),
     "ccal_set_pose_init": (C.c_int, [C.c_void_p, C.c_int32]),

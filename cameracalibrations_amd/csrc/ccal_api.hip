@@ -139,6 +139,7 @@ struct ccal_ctx {
     // small drop-in calls (ccal_calibrate): inputs staged in the pinned block and copied by a kernel, poses written to it by the launch
     // that ends the solve -- no copy command, no read-back launch, one wait.  Layout of h_pin: template | corners | poses
     bool small_call = false;
+    CopySeg *defer_copy = nullptr; // ccal_calibrate_many: the staged inputs' copy is described here instead of launched (one launch for all)
     size_t obj_staged = 0;        // words of the template waiting in the pinned block for the corners' copy launch (small calls only)
     double *host_poses = nullptr;
     bool use_solo = true;         // fits of a few images on one GPU run all their trials in ONE launch (CCAL_NO_SOLO=1: launch per trial)
@@ -529,8 +530,14 @@ int ccal_set_image_points(ccal_ctx *c, const float *img_host) {
     }
     if (c->small_call && need <= PIN_IMG_BYTES) {
         memcpy(static_cast<char *>(c->h_pin) + PIN_IMG_OFF, img_host, need);
-        HIPCHK(launch_copy_words2(c->stream, static_cast<char *>(c->h_pin) + PIN_OBJ_OFF, c->d_obj, c->obj_staged,
-                                  static_cast<char *>(c->h_pin) + PIN_IMG_OFF, c->d_img_own, need / 4));
+        if (c->defer_copy != nullptr) {
+            *c->defer_copy = CopySeg{reinterpret_cast<const uint32_t *>(static_cast<char *>(c->h_pin) + PIN_OBJ_OFF), reinterpret_cast<uint32_t *>(c->d_obj),
+                                     c->obj_staged, reinterpret_cast<const uint32_t *>(static_cast<char *>(c->h_pin) + PIN_IMG_OFF),
+                                     reinterpret_cast<uint32_t *>(c->d_img_own), need / 4};
+        } else {
+            HIPCHK(launch_copy_words2(c->stream, static_cast<char *>(c->h_pin) + PIN_OBJ_OFF, c->d_obj, c->obj_staged,
+                                      static_cast<char *>(c->h_pin) + PIN_IMG_OFF, c->d_img_own, need / 4));
+        }
         c->obj_staged = 0;
     } else {
         if (c->obj_staged) {
@@ -1175,6 +1182,16 @@ int ccal_get_init(ccal_ctx *c, double intr[CCAL_NINTR], double *rt_host) {
 // One context per (host thread, device) is kept alive between ccal_calibrate calls: creating the
 // stream, ~15 device buffers and the launch graph costs far more than a small fit.
 static thread_local ccal_ctx *t_cached[16] = {nullptr};
+static thread_local std::vector<ccal_ctx *> t_pool[16];   // ccal_calibrate_many's contexts, per device
+static thread_local CopySeg *t_segs = nullptr;            // ... and its table of staged-input copies (pinned, device-visible)
+static thread_local size_t t_segs_cap = 0;
+struct MergeArena {
+    int device = -1;
+    char *d = nullptr, *h = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+};
+static thread_local MergeArena t_arena;
 
 // ... and one set of contexts per (host thread, device list) for ccal_calibrate_multi
 struct MultiSet {
@@ -1197,6 +1214,15 @@ static void multi_destroy(MultiSet &m) {
 
 void ccal_thread_cleanup(void) {
     for (auto &c : t_cached) { if (c) ccal_destroy(c); c = nullptr; }
+    for (auto &pool : t_pool) { for (auto c : pool) ccal_destroy(c); pool.clear(); }
+    if (t_segs) { (void)hipHostFree(t_segs); t_segs = nullptr; t_segs_cap = 0; }
+    if (t_arena.d) {
+        (void)hipSetDevice(t_arena.device);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(t_arena.d); (void)hipHostFree(t_arena.h);
+        if (t_arena.ev) (void)hipEventDestroy(t_arena.ev);
+        t_arena = MergeArena();
+    }
     for (auto &m : t_multi) multi_destroy(m);
     t_multi.clear();
 }
@@ -1363,8 +1389,7 @@ int ccal_fit(ccal_ctx *c) {
 // host-side bookkeeping, the per-context progress words and results are exactly those of ccal_fit.
 static bool merge_ok(const ccal_ctx *c) {
     if (!c || !c->use_merge || c->time_sweeps || sharded(c) || c->p2p_split || !focal_exact(c) || c->init_hmode == 0 || !c->planar_z0 ||
-        (c->flags & CCAL_USE_INTRINSIC_GUESS) != 0 || c->foc_dirty || c->focal_pending || c->acc_dirty || !c->have_problem || !c->have_img ||
-        c->host_poses != nullptr)
+        (c->flags & CCAL_USE_INTRINSIC_GUESS) != 0 || c->foc_dirty || c->focal_pending || c->acc_dirty || !c->have_problem || !c->have_img)
         return false;
     if ((size_t)32 * c->P + sizeof(double) * 2200 > 60 * 1024) return false;               // (the pose kernel's staged-correspondence form)
     // (a fit of more workgroups fills half the chip alone: merged with others every launch boundary waits for the slowest of them, and
@@ -1372,13 +1397,7 @@ static bool merge_ok(const ccal_ctx *c) {
     return ((long)c->N * c->wpi + 3) / 4 <= 128;
 }
 
-struct MergeArena {
-    int device = -1;
-    char *d = nullptr, *h = nullptr;
-    size_t cap = 0;
-    hipEvent_t ev = nullptr;
-};
-static thread_local MergeArena t_arena;
+
 
 static int arena_need(MergeArena &A, int device, size_t bytes) {
     if (A.device == device && bytes <= A.cap) return CCAL_OK;
@@ -1551,6 +1570,104 @@ int ccal_fit_many(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out) {
     }
     if (dbg && dbg_calls % 20 == 0) fprintf(stderr, "[ccal] fit_many: waits + checks %.1f us for %d contexts\n", 1e6 * (now_s() - t_end0), n);
     if (worst < 0) g_err = worst_err;
+    return worst;
+}
+
+// fit_model for n calibrations of one caller (shared template, image size, flags, criteria), host arrays in and out like
+// ccal_calibrate: a pool of contexts of this thread, small inputs staged through each context's pinned block on ONE stream (a copy
+// launch each, no waits), the fits through ccal_fit_many (merged launches), the poses written to the pinned blocks by the launches
+// that end the solves -- one wait per calibration on a word that is long since set.
+int ccal_calibrate_many(const float *obj, int32_t P, int32_t n, const float *const *img, const int32_t *N, int32_t width, int32_t height,
+                        double aspect, uint32_t flags, int32_t max_iter, double eps, int32_t device, double *const *out,
+                        int32_t *status_out) {
+    if (!obj || n < 0 || (n > 0 && (!img || !N || !out))) return fail(CCAL_E_ARG, "ccal_calibrate_many: NULL argument");
+    if (device < 0 || device >= 16) return fail(CCAL_E_ARG, "ccal_calibrate_many: bad device index");
+    if (flags & CCAL_USE_INTRINSIC_GUESS) return fail(CCAL_E_ARG, "ccal_calibrate_many: no intrinsic guess in the batched form (use ccal_calibrate)");
+    auto &pool = t_pool[device];
+    while ((int)pool.size() < n) {
+        ccal_ctx *c = nullptr;
+        const int rc = ccal_create(device, &c);
+        if (rc < 0) return rc;
+        pool.push_back(c);
+        (void)&t_cache_guard;          // (released at thread exit)
+    }
+    if (n == 0) return CCAL_OK;
+    HIPCHK(hipSetDevice(device));
+    if ((size_t)n > t_segs_cap) {
+        HIPCHK(hipStreamSynchronize(pool[0]->own_stream));      // (the last call's copy launch has read the old table)
+        if (t_segs) (void)hipHostFree(t_segs);
+        t_segs = nullptr; t_segs_cap = 0;
+        HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&t_segs), sizeof(CopySeg) * ((size_t)n + 64), hipHostMallocMapped));
+        t_segs_cap = (size_t)n + 64;
+    }
+    int n_segs = 0;
+    hipStream_t shared = pool[0]->own_stream;
+    std::vector<int> st((size_t)n, CCAL_OK);
+    std::vector<std::string> errs((size_t)n);
+    std::vector<ccal_ctx *> live;
+    std::vector<int> live_i;
+    static const bool no_small = getenv("CCAL_NO_SMALL_CALL") != nullptr;
+    for (int i = 0; i < n; i++) {
+        ccal_ctx *c = pool[i];
+        if (!img[i] || !out[i] || N[i] < 1) { st[i] = fail(CCAL_E_ARG, "ccal_calibrate_many: NULL / empty calibration"); errs[i] = g_err; continue; }
+        c->small_call = P >= 1 && sizeof(float) * 3 * (size_t)P <= PIN_OBJ_BYTES && sizeof(float) * 2 * (size_t)P * N[i] <= PIN_IMG_BYTES &&
+                        sizeof(double) * 8 * (size_t)N[i] <= PIN_POSE_BYTES && !no_small;
+        c->host_poses = c->small_call ? reinterpret_cast<double *>(static_cast<char *>(c->h_pin) + PIN_POSE_OFF) : nullptr;
+        // small inputs: staged and copied on the one stream the merged launches will run on, nothing waited for; larger ones: their own
+        // stream, uploaded before this loop goes on (the merged launches would not wait for another stream's copies)
+        c->stream = c->small_call ? shared : c->own_stream;
+        c->defer_sync = c->small_call;
+        c->defer_copy = c->small_call ? t_segs + n_segs : nullptr;     // (one copy launch for all of them, below)
+        int rc = ccal_set_problem(c, obj, P, N[i], width, height, aspect, flags, max_iter, eps);
+        if (rc >= 0 && (rc = ccal_set_image_points(c, img[i])) < 0) { c->have_problem = false; c->obj_staged = 0; }
+        c->defer_sync = false;
+        if (rc >= 0 && c->defer_copy != nullptr) n_segs++;
+        c->defer_copy = nullptr;
+        if (rc < 0) { st[i] = rc; errs[i] = g_err; continue; }
+        live.push_back(c);
+        live_i.push_back(i);
+    }
+    if (n_segs > 0 && launch_copy_multi(shared, t_segs, n_segs) != hipSuccess) {
+        (void)hipStreamSynchronize(shared);
+        for (int i = 0; i < n; i++) { pool[i]->small_call = false; pool[i]->host_poses = nullptr; pool[i]->stream = pool[i]->own_stream; pool[i]->have_problem = false; }
+        return fail(CCAL_E_DEVICE, "ccal_calibrate_many: copy launch failed");
+    }
+    std::vector<int32_t> st_live(live.size(), 0);
+    (void)ccal_fit_many(live.data(), (int32_t)live.size(), st_live.data());
+    const std::string many_err = g_err;
+    for (size_t q = 0; q < live.size(); q++) {
+        ccal_ctx *c = live[q];
+        const int i = live_i[q];
+        int rc = st_live[q];
+        if (rc < 0) { st[i] = rc; errs[i] = many_err; continue; }
+        double *o = out[i];
+        const double *pose_rows = c->host_poses;      // written by the launch that found the solve done, ahead of its progress word
+        if (pose_rows == nullptr) {
+            int r2;
+            if ((r2 = stage_need(c, sizeof(double) * 8 * (size_t)c->N)) < 0 || (r2 = enqueue_pose_rows(c, static_cast<double *>(c->h_stage))) < 0 ||
+                (r2 = signal_and_spin(c)) < 0) { st[i] = r2; errs[i] = g_err; continue; }
+            pose_rows = static_cast<const double *>(c->h_stage);
+        }
+        double intr[9];
+        ccal_stats s9;
+        int r3 = ccal_get_result(c, intr, nullptr, nullptr, &s9);
+        if (r3 < 0) { st[i] = r3; errs[i] = g_err; continue; }
+        memcpy(o, intr, sizeof(double) * 9);
+        o[9] = s9.rms;
+        o[10] = (double)s9.iters;
+        unpack_pose_rows(c, pose_rows, o + 11, o + 11 + (size_t)3 * c->N);
+        st[i] = rc;
+    }
+    int worst = CCAL_OK;
+    for (int i = 0; i < n; i++) {
+        ccal_ctx *c = pool[i];
+        c->small_call = false;
+        c->host_poses = nullptr;
+        c->stream = c->own_stream;
+        if (status_out) status_out[i] = st[i];
+        if (st[i] < 0 && worst >= 0) { worst = st[i]; g_err = "calibration " + std::to_string(i) + ": " + errs[i]; }
+        else if (st[i] > worst && worst >= 0) worst = st[i];
+    }
     return worst;
 }
 

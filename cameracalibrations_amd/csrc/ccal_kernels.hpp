@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <vector>
 
 #include "ccal_p2p.hpp"
@@ -125,6 +126,8 @@ hipError_t launch_map_inverse(hipStream_t stream, const double *rc, double *xyz,
 hipError_t launch_signal(hipStream_t stream, unsigned long long *flag, unsigned long long value);   // pinned completion word
 // n 32-bit words src -> dst by a kernel on `stream` (src: pinned, device-mapped host memory a small call staged its inputs in)
 hipError_t launch_copy_words(hipStream_t stream, const void *src, void *dst, size_t n_words);
+struct CopySeg { const uint32_t *src1; uint32_t *dst1; size_t n1; const uint32_t *src2; uint32_t *dst2; size_t n2; };
+hipError_t launch_copy_multi(hipStream_t stream, const CopySeg *segs, int n);   // segs: device-visible (pinned, mapped) memory
 hipError_t launch_copy_words2(hipStream_t stream, const void *src1, void *dst1, size_t n1, const void *src2, void *dst2, size_t n2);
 // intr[9], fail[4] (device) -> pinned host memory, by a kernel on `stream`
 hipError_t launch_init_readback(hipStream_t stream, const double *intr, const int *fail, double *host_intr, int *host_fail);

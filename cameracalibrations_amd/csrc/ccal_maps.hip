@@ -238,6 +238,20 @@ hipError_t launch_copy_words2(hipStream_t stream, const void *src1, void *dst1, 
     return hipGetLastError();
 }
 
+// the staged inputs of many small calls in one launch: workgroup b copies segment pair b (table in device-visible pinned memory)
+__global__ __launch_bounds__(256) void k_copy_multi(const CopySeg *__restrict__ segs) {
+    const CopySeg s = segs[blockIdx.x];
+    for (size_t i = threadIdx.x; i < s.n1 + s.n2; i += 256) {
+        if (i < s.n1) s.dst1[i] = s.src1[i];
+        else s.dst2[i - s.n1] = s.src2[i - s.n1];
+    }
+}
+hipError_t launch_copy_multi(hipStream_t stream, const CopySeg *segs, int n) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_copy_multi, dim3(n), dim3(256), 0, stream, segs);
+    return hipGetLastError();
+}
+
 hipError_t launch_copy_words(hipStream_t stream, const void *src, void *dst, size_t n_words) {
     if (n_words == 0) return hipSuccess;
     const int grid = (int)std::min<size_t>((n_words + 255) / 256, 64);

@@ -319,36 +319,35 @@ def fit_many(solvers, check=True):
     return [int(v) for v in st]
 
 
-_pool = {}    # device -> Solvers kept for fit_models (a context holds its buffers and captured graph between calls)
-
-
 def fit_models(sz, objpoints, imgpointsss, n_corners, with_distortion, aspect, device=0):
     """`fit_model` (src/detect_fit.jl:27-61) for several calibrations at once -- the loop a caller with many cameras runs around
     src/buildcalibrations.jl:12-26: imgpointsss = one list / array of per-image corners PER calibration (the template, image size,
-    flags and aspect are shared, as one caller's are).  Returns a list of fit_model's namespaces, the same values fit_model
-    returns for each set on its own."""
+    flags and aspect are shared, as one caller's are).  One call of ccal_calibrate_many: host arrays in and out, the library's own
+    pool of contexts, the fits through ccal_fit_many (small ones share merged launches).  Returns a list of fit_model's namespaces,
+    the same values fit_model returns for each set on its own."""
     P = int(n_corners[0]) * int(n_corners[1])
-    obj = np.asarray(objpoints, dtype=np.float32).reshape(P, 3)
-    pool = _pool.setdefault(int(device), [])
-    while len(pool) < len(imgpointsss):
-        pool.append(Solver(device))
-    used = pool[:len(imgpointsss)]
-    for s, pts in zip(used, imgpointsss):
-        if isinstance(pts, np.ndarray):
-            img = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, P, 2)
-        else:
-            img = np.stack([np.asarray(m, dtype=np.float32).reshape(P, 2) for m in pts])
-        s.set_problem(obj, img.shape[0], (int(sz[0]), int(sz[1])), aspect=float(aspect), flags=reference_flags(with_distortion),
-                      max_iter=CRITERIA[0], eps=CRITERIA[1])
-        s.set_image_points(img)
-    fit_many(used)
-    out = []
-    for s in used:
-        r = s.result()
-        out.append(SimpleNamespace(k=float(r["intr"][4]), Rs=list(r["rvecs"]), ts=list(r["tvecs"]), frow=float(r["intr"][0]),
-                                   fcol=float(r["intr"][1]), crow=float(r["intr"][2]), ccol=float(r["intr"][3]), rms=r["rms"],
-                                   iters=r["iters"], stats={k: v for k, v in r.items() if k not in ("intr", "K4", "dist5", "rvecs", "tvecs")}))
-    return out
+    obj = np.ascontiguousarray(objpoints, dtype=np.float32).reshape(P, 3)
+    imgs = []
+    for pts in imgpointsss:
+        try:
+            imgs.append(np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, P, 2))
+        except ValueError:
+            imgs.append(np.stack([np.asarray(m, dtype=np.float32).reshape(P, 2) for m in pts]))
+    n = len(imgs)
+    outs = [np.zeros(11 + 6 * a.shape[0]) for a in imgs]
+    Ns = (C.c_int32 * n)(*[a.shape[0] for a in imgs])
+    ip = (C.c_void_p * n)(*[a.ctypes.data for a in imgs])
+    op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    st = (C.c_int32 * n)()
+    F.check(F.lib().ccal_calibrate_many(F.f32(obj)[1], P, n, ip, Ns, int(sz[0]), int(sz[1]), float(aspect), reference_flags(with_distortion),
+                                        CRITERIA[0], CRITERIA[1], int(device), op, st))
+    res = []
+    for o, a in zip(outs, imgs):
+        N = a.shape[0]
+        res.append(SimpleNamespace(k=float(o[4]), Rs=list(o[11:11 + 3 * N].reshape(N, 3)), ts=list(o[11 + 3 * N:].reshape(N, 3)),
+                                   frow=float(o[0]), fcol=float(o[1]), crow=float(o[2]), ccol=float(o[3]), rms=float(o[9]), iters=int(o[10]),
+                                   stats={"rms": float(o[9]), "iters": int(o[10])}))
+    return res
 
 
 def debug_multi_set_epoch(devices, epoch):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CCAL_VERSION 104 /* 0.1.4: ccal_fit_many; 0.1.3: ccal_stats.sweep_form (was padding); 0.1.2: ccal_p2p_export2 / ccal_p2p_connect2, ccal_p2p_set_exchange mode 2 */
+#define CCAL_VERSION 104 /* 0.1.4: ccal_fit_many, ccal_calibrate_many; 0.1.3: ccal_stats.sweep_form (was padding); 0.1.2: ccal_p2p_export2 / ccal_p2p_connect2, ccal_p2p_set_exchange mode 2 */
 
 /* status codes */
 #define CCAL_OK            0
@@ -209,6 +209,15 @@ int  ccal_fit(ccal_ctx *ctx);
  * NULL) = what ccal_fit would have returned for context i; the return value is the first failure, else the largest
  * warning; ccal_last_error() then names that context. */
 int  ccal_fit_many(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out);
+/* ccal_calibrate (= fit_model, src/detect_fit.jl:27-61) for n calibrations of one caller: template obj [P][3], image size, aspect,
+ * flags and criteria shared; img[i] -> [N[i]][P][2] float32 corners of calibration i; results packed per calibration into
+ * out[i]: K4 (4) | dist5 (5) | rms | iters | rvecs [N[i]][3] | tvecs [N[i]][3]   (11 + 6 N[i] doubles).
+ * Host arrays in and out; contexts come from a pool of the calling thread (released by ccal_thread_cleanup / at thread exit);
+ * the fits run through ccal_fit_many.  Same values as n calls of ccal_calibrate.  status_out[i] (may be NULL) per calibration;
+ * returns the first failure, else the largest warning.  CCAL_USE_INTRINSIC_GUESS is not supported here (CCAL_E_ARG). */
+int  ccal_calibrate_many(const float *obj, int32_t P, int32_t n, const float *const *img, const int32_t *N, int32_t width,
+                         int32_t height, double aspect, uint32_t flags, int32_t max_iter, double eps, int32_t device,
+                         double *const *out, int32_t *status_out);
 /* Bracket every sweep launch of the next ccal_lm_run calls with a HIP event pair on the launch
  * stream and report the mean in ccal_stats.sweep_us (roofline figure of bench.py). */
 int  ccal_set_sweep_timing(ccal_ctx *ctx, int32_t enable);

@@ -91,35 +91,35 @@ end
     fit_models(sz, objpoints, imgpointsss, n_corners, with_distortion, aspect)
 
 `fit_model` for several calibrations at once (one vector of per-image corner matrices per calibration; template, image size and
-flags shared): one context per calibration, every pipeline enqueued before any is waited for (`ccal_fit_many`) -- the loop a
-caller with many cameras runs around src/buildcalibrations.jl:12-26.  Returns a vector of `fit_model`'s NamedTuples.
+flags shared) in one call of `ccal_calibrate_many` -- the loop a caller with many cameras runs around
+src/buildcalibrations.jl:12-26; small fits share merged launches on the device.  Returns a vector of `fit_model`'s NamedTuples.
 """
 function fit_models(sz, objpoints, imgpointsss, n_corners, with_distortion, aspect; device = 0)
     P = prod(n_corners)
     obj = Float32.(reshape(reinterpret(reshape, eltype(eltype(objpoints)), vec(objpoints)), 3, P))   # [3,P]
     flags = ZERO_TANGENT_DIST | FIX_K3 | FIX_K2 | (with_distortion ? 0x0 : FIX_K1) | FIX_ASPECT_RATIO
-    ctxs = [Context(device) for _ in imgpointsss]
-    for (c, imgpointss) in zip(ctxs, imgpointsss)
-        N = length(imgpointss)
-        img = Array{Float32}(undef, 2, P, N)                                                     # [2,P,N]
+    imgs = map(imgpointsss) do imgpointss
+        img = Array{Float32}(undef, 2, P, length(imgpointss))                                    # [2,P,N]
         for (i, m) in enumerate(imgpointss), (p, rc) in enumerate(vec(m))
             img[1, p, i] = rc[1]; img[2, p, i] = rc[2]
         end
-        check(ccall((:ccal_set_problem, LIB), Int32,
-                    (Ptr{Cvoid}, Ptr{Float32}, Int32, Int32, Int32, Int32, Float64, UInt32, Int32, Float64),
-                    c.h, obj, P, N, sz[1], sz[2], Float64(aspect), flags, CRITERIA[1], CRITERIA[2]))
-        check(ccall((:ccal_set_image_points, LIB), Int32, (Ptr{Cvoid}, Ptr{Float32}), c.h, img))
+        img
     end
-    hs = [c.h for c in ctxs]
-    GC.@preserve ctxs check(ccall((:ccal_fit_many, LIB), Int32, (Ptr{Ptr{Cvoid}}, Int32, Ptr{Int32}), hs, length(hs), C_NULL))
-    return map(zip(ctxs, imgpointsss)) do (c, imgpointss)
-        N = length(imgpointss)
-        intr = zeros(Float64, 9); rvecs = zeros(Float64, 3, N); tvecs = zeros(Float64, 3, N)
-        check(ccall((:ccal_get_result, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Cvoid}),
-                    c.h, intr, rvecs, tvecs, C_NULL))
-        frow, fcol, crow, ccol = intr[1:4]
-        k = intr[5]
-        (; k, Rs = [rvecs[:, i] for i in 1:N], ts = [tvecs[:, i] for i in 1:N], frow, fcol, crow, ccol)
+    Ns = Int32[size(img, 3) for img in imgs]
+    outs = [zeros(Float64, 11 + 6 * N) for N in Ns]           # K4 | dist5 | rms | iters | rvecs [3,N] | tvecs [3,N]
+    GC.@preserve imgs outs begin
+        ip = Ptr{Cvoid}[pointer(img) for img in imgs]
+        op = Ptr{Cvoid}[pointer(o) for o in outs]
+        check(ccall((:ccal_calibrate_many, LIB), Int32,
+                    (Ptr{Float32}, Int32, Int32, Ptr{Ptr{Cvoid}}, Ptr{Int32}, Int32, Int32, Float64, UInt32, Int32, Float64, Int32,
+                     Ptr{Ptr{Cvoid}}, Ptr{Int32}),
+                    obj, P, length(imgs), ip, Ns, sz[1], sz[2], Float64(aspect), flags, CRITERIA[1], CRITERIA[2], device, op, C_NULL))
+    end
+    return map(zip(outs, Ns)) do (o, N)
+        frow, fcol, crow, ccol = o[1:4]
+        k = o[5]
+        rv = reshape(o[12:11 + 3N], 3, N); tv = reshape(o[12 + 3N:end], 3, N)
+        (; k, Rs = [rv[:, i] for i in 1:N], ts = [tv[:, i] for i in 1:N], frow, fcol, crow, ccol)
     end
 end
 

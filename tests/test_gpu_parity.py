@@ -1390,8 +1390,10 @@ def test_fit_many_equals_one_fit_at_a_time(golden_dir):
     from cameracalibrations_amd import board_template
     obj = board_template(ex["n_corners"])
     imgs = [np.array(m, dtype=np.float64) for m in ex["corners"]]
-    sets = [imgs, imgs[:4], imgs[1:], imgs[::-1]]
-    many = fit_models(ex["image_size_wh"], obj, sets, ex["n_corners"], True, 1)
+    sets = [imgs, imgs[:4], imgs[1:], imgs[::-1], imgs[:2], imgs[2:]]
+    assert fit_models(ex["image_size_wh"], obj, [], ex["n_corners"], True, 1) == []
+    assert len(fit_models(ex["image_size_wh"], obj, sets[:2], ex["n_corners"], True, 1)) == 2       # (two: streams of their own)
+    many = fit_models(ex["image_size_wh"], obj, sets, ex["n_corners"], True, 1)                        # (six: merged launches)
     for sub, a in zip(sets, many):
         b = fit_model(ex["image_size_wh"], obj, sub, ex["n_corners"], True, 1)
         assert (a.frow, a.fcol, a.crow, a.ccol, a.k, a.rms, a.iters) == (b.frow, b.fcol, b.crow, b.ccol, b.k, b.rms, b.iters)
