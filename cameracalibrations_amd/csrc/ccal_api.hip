@@ -1397,8 +1397,6 @@ static bool merge_ok(const ccal_ctx *c) {
     return ((long)c->N * c->wpi + 3) / 4 <= 128;
 }
 
-
-
 static int arena_need(MergeArena &A, int device, size_t bytes) {
     if (A.device == device && bytes <= A.cap) return CCAL_OK;
     if (A.d) { (void)hipSetDevice(A.device); (void)hipDeviceSynchronize(); (void)hipFree(A.d); (void)hipHostFree(A.h); A.d = A.h = nullptr; A.cap = 0; }
@@ -1408,6 +1406,7 @@ static int arena_need(MergeArena &A, int device, size_t bytes) {
         HIPCHK(hipEventCreateWithFlags(&A.ev, hipEventDisableTiming));
     }
     const size_t cap = bytes + bytes / 2 + 65536;
+    (void)&t_cache_guard;                         // (the arena is released with this thread's caches: ccal_thread_cleanup)
     HIPCHK(hipMalloc(&A.d, cap));
     HIPCHK(hipHostMalloc(&A.h, cap, hipHostMallocDefault));
     A.cap = cap;
@@ -1538,10 +1537,9 @@ int ccal_fit_many(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out) {
             return fail(CCAL_E_STATE, "ccal_fit_many: a context is a shard of a joint fit (its peers' launches would have to be enqueued too)");
     std::vector<FitPhase> ph((size_t)n);
     const double t0 = now_s();
+    // steady-state contexts of one device with small fits: merged launches; the others: their own pipelines on their own streams
     // (enqueued by this one thread: helper threads enqueueing beside it were measured -- 2 and 4 threads, 32 contexts -- and changed
-    //  nothing: the runtime serialises launch calls.  A pipeline costs the host ~14 us of launch calls, which is what bounds a batch
-    //  of small fits: tools/many_timing.py)
-    // steady-state contexts of one device: merged launches; the others: their own pipelines on their own streams
+    //  nothing, the runtime serialises launch calls; a pipeline of its own costs the host ~14 us of launch calls, a recorded one 1.5)
     std::vector<char> merged((size_t)n, 0);
     for (int dev = 0; dev < 16 && n > 1; dev++) {
         std::vector<int> idx;
