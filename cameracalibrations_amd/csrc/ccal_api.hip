@@ -1191,7 +1191,7 @@ struct MergeArena {
     size_t cap = 0;
     hipEvent_t ev = nullptr;
 };
-static thread_local MergeArena t_arena;
+static thread_local MergeArena t_arena[2];   // tables of the merged initialisation launches | of the merged solves
 
 // ... and one set of contexts per (host thread, device list) for ccal_calibrate_multi
 struct MultiSet {
@@ -1216,13 +1216,14 @@ void ccal_thread_cleanup(void) {
     for (auto &c : t_cached) { if (c) ccal_destroy(c); c = nullptr; }
     for (auto &pool : t_pool) { for (auto c : pool) ccal_destroy(c); pool.clear(); }
     if (t_segs) { (void)hipHostFree(t_segs); t_segs = nullptr; t_segs_cap = 0; }
-    if (t_arena.d) {
-        (void)hipSetDevice(t_arena.device);
-        (void)hipDeviceSynchronize();
-        (void)hipFree(t_arena.d); (void)hipHostFree(t_arena.h);
-        if (t_arena.ev) (void)hipEventDestroy(t_arena.ev);
-        t_arena = MergeArena();
-    }
+    for (auto &A : t_arena)
+        if (A.d) {
+            (void)hipSetDevice(A.device);
+            (void)hipDeviceSynchronize();
+            (void)hipFree(A.d); (void)hipHostFree(A.h);
+            if (A.ev) (void)hipEventDestroy(A.ev);
+            A = MergeArena();
+        }
     for (auto &m : t_multi) multi_destroy(m);
     t_multi.clear();
 }
@@ -1327,21 +1328,30 @@ int ccal_calibrate(const float *obj, const float *img, int32_t P, int32_t N, int
 // before the second half of any.
 struct FitPhase { bool guess = false; int rc = CCAL_OK; int lm_rc = CCAL_OK; bool lm_begun = false; std::string err; };
 
-static void fit_begin(ccal_ctx *c, FitPhase &ph) {
+// (the enqueueing half itself in two steps -- the initialisation stages | the solve's launches --, so that merged launches can put the
+//  first step of every context on the device before the second step of any is even recorded)
+static void fit_begin_init(ccal_ctx *c, FitPhase &ph) {
     ph = FitPhase();
     if (!c) { ph.rc = fail(CCAL_E_ARG, "ccal_fit: ctx == NULL"); ph.err = g_err; return; }
     if (!c->have_problem || !c->have_img) { ph.rc = fail(CCAL_E_STATE, "ccal_fit: problem / image points not set"); ph.err = g_err; return; }
     ph.guess = (c->flags & CCAL_USE_INTRINSIC_GUESS) != 0;
     if (ph.guess && !c->have_intr) { ph.rc = fail(CCAL_E_STATE, "ccal_fit: USE_INTRINSIC_GUESS without ccal_set_intrinsics"); ph.err = g_err; return; }
     c->defer_sync = true;
-    do {
-        if (!ph.guess && (ph.rc = ccal_init_intrinsics(c)) < 0) break;
-        if ((ph.rc = ccal_init_extrinsics(c)) < 0) break;
-        ph.lm_rc = lm_begin(c);        // (its first launch carries the init stages' flags and intrinsics to the host)
-        ph.lm_begun = ph.lm_rc == CCAL_OK;
-    } while (0);
+    if (ph.guess || (ph.rc = ccal_init_intrinsics(c)) >= 0) ph.rc = ccal_init_extrinsics(c);
     c->defer_sync = false;
-    if (ph.rc < 0 || ph.lm_rc < 0) ph.err = g_err;
+    if (ph.rc < 0) ph.err = g_err;
+}
+
+static void fit_begin_lm(ccal_ctx *c, FitPhase &ph) {
+    if (!c || ph.rc < 0) return;
+    ph.lm_rc = lm_begin(c);            // (its first launch carries the init stages' flags and intrinsics to the host)
+    ph.lm_begun = ph.lm_rc == CCAL_OK;
+    if (ph.lm_rc < 0) ph.err = g_err;
+}
+
+static void fit_begin(ccal_ctx *c, FitPhase &ph) {
+    fit_begin_init(c, ph);
+    fit_begin_lm(c, ph);
 }
 
 static int fit_end(ccal_ctx *c, FitPhase &ph) {
@@ -1421,41 +1431,30 @@ static void merge_poison(ccal_ctx *c) {           // a recording was abandoned: 
     c->acc_dirty = true;
 }
 
-// the enqueueing half of every context in `idx` (same device, all merge_ok) as merged launches on the first one's stream.
+// the enqueueing half of every context in `idx` (same device, all merge_ok) as merged launches on the first one's stream, in two
+// steps: the initialisation stages of ALL contexts are recorded, merged and launched; while they run the solves are recorded, merged
+// and launched behind them.
 // false: nothing was launched and every context of `idx` is back in a state the ordinary fit_begin handles.
 static bool fit_begin_merged(ccal_ctx *const *ctxs, const std::vector<int> &idx, std::vector<FitPhase> &ph) {
     const int m = (int)idx.size();
     std::vector<MergeRecorder> rec((size_t)m);
-    bool ok = true;
     static const bool dbg = getenv("CCAL_DEBUG_TIMING") != nullptr;
-    const double t_rec0 = now_s();
-    for (int e = 0; e < m; e++) {
-        ccal_ctx *c = ctxs[idx[e]];
-        merge_recorder() = &rec[e];
-        c->recording = true;
-        fit_begin(c, ph[idx[e]]);
-        c->recording = false;
-        merge_recorder() = nullptr;
-        const FitPhase &p = ph[idx[e]];
-        if (rec[e].unsupported || p.rc < 0 || p.lm_rc < 0 || !p.lm_begun || rec[e].recs.size() < 3 || rec[e].recs[0].kernel != MERGE_HOMOGRAPHY ||
-            rec[e].recs[1].kernel != MERGE_EXTRINSICS || rec[e].recs[2].kernel != MERGE_LM)
-            ok = false;
-    }
-    const double t_rec1 = now_s();
-    size_t len = 0;
-    for (int e = 0; e < m && ok; e++) {
-        len = std::max(len, rec[e].recs.size());
-        for (size_t j = 2; j < rec[e].recs.size(); j++) ok = ok && rec[e].recs[j].kernel == MERGE_LM;
-    }
     ccal_ctx *c0 = ctxs[idx[0]];
-    MergeArena &A = t_arena;
-    // layout: three tables (entry = context), then per launch: map [grid] | first [m] | nblk [m]
     struct Launch { int kernel, key, grid, k, first, final_only; size_t pos, dyn, off_map, off_first, off_nblk; std::vector<int> who; };
-    std::vector<Launch> launches;
-    size_t off_tab[3] = {0, 0, 0}, bytes = 0;
-    if (ok) {
-        for (int t = 0; t < 3; t++) { off_tab[t] = bytes; bytes += ((rec[0].recs[t].args_bytes * (size_t)m + 255) / 256) * 256; }
-        for (size_t j = 0; j < len; j++) {
+
+    // records [lo, hi) of every context -> tables (one per kernel kind in `kinds`, entry = context) + launches, through arena A
+    auto merge_and_launch = [&](MergeArena &A, size_t lo, size_t hi, std::initializer_list<int> kinds, size_t &n_launches) -> hipError_t {
+        std::vector<Launch> launches;
+        size_t off_tab[3] = {0, 0, 0}, bytes = 0;
+        for (int t : kinds) {
+            size_t ab = 0;
+            for (int e = 0; e < m && ab == 0; e++)
+                for (size_t j = lo; j < std::min(hi, rec[e].recs.size()); j++)
+                    if (rec[e].recs[j].kernel == t) { ab = rec[e].recs[j].args_bytes; break; }
+            off_tab[t] = bytes;
+            bytes += ((ab * (size_t)m + 255) / 256) * 256;
+        }
+        for (size_t j = lo; j < hi; j++)
             for (int e = 0; e < m; e++) {
                 if (j >= rec[e].recs.size()) continue;
                 const MergeRecord &r = rec[e].recs[j];
@@ -1470,17 +1469,20 @@ static bool fit_begin_merged(ccal_ctx *const *ctxs, const std::vector<int> &idx,
                 L->grid += r.grid;
                 L->dyn = std::max(L->dyn, r.dyn_lds);
             }
-        }
         for (auto &L : launches) {
             L.off_map = bytes; bytes += (((size_t)L.grid * 4 + 255) / 256) * 256;
             L.off_first = bytes; bytes += (((size_t)m * 4 + 255) / 256) * 256;
             L.off_nblk = bytes; bytes += (((size_t)m * 4 + 255) / 256) * 256;
         }
-        ok = arena_need(A, c0->device, bytes) == CCAL_OK;
-    }
-    if (ok) {
-        for (int t = 0; t < 3; t++)
-            for (int e = 0; e < m; e++) memcpy(A.h + off_tab[t] + rec[e].recs[t].args_bytes * (size_t)e, rec[e].recs[t].args, rec[e].recs[t].args_bytes);
+        if (arena_need(A, c0->device, bytes) != CCAL_OK) return hipErrorOutOfMemory;
+        if (A.ev != nullptr && hipEventSynchronize(A.ev) != hipSuccess) return hipErrorUnknown;     // (the last call's launches have read the old tables)
+        for (int t : kinds)
+            for (int e = 0; e < m; e++)
+                for (size_t j = lo; j < std::min(hi, rec[e].recs.size()); j++)
+                    if (rec[e].recs[j].kernel == t) {     // (the first record of that kind: a solve's later launches differ in k / first / final_only only)
+                        memcpy(A.h + off_tab[t] + rec[e].recs[j].args_bytes * (size_t)e, rec[e].recs[j].args, rec[e].recs[j].args_bytes);
+                        break;
+                    }
         for (auto &L : launches) {
             int *map = reinterpret_cast<int *>(A.h + L.off_map), *first = reinterpret_cast<int *>(A.h + L.off_first),
                 *nblk = reinterpret_cast<int *>(A.h + L.off_nblk);
@@ -1493,38 +1495,81 @@ static bool fit_begin_merged(ccal_ctx *const *ctxs, const std::vector<int> &idx,
                 b += g;
             }
         }
-        ok = hipSetDevice(c0->device) == hipSuccess && (A.ev == nullptr || hipEventSynchronize(A.ev) == hipSuccess) &&
-             hipMemcpyAsync(A.d, A.h, bytes, hipMemcpyHostToDevice, c0->stream) == hipSuccess;
-        // (from here on launches are in flight: a failure is a HIP error and fails the contexts, it cannot fall back)
-        if (ok) {
-            hipError_t he = hipSuccess;
-            for (auto &L : launches) {
-                const int *map = reinterpret_cast<const int *>(A.d + L.off_map), *first = reinterpret_cast<const int *>(A.d + L.off_first),
-                          *nblk = reinterpret_cast<const int *>(A.d + L.off_nblk);
-                if (L.kernel == MERGE_HOMOGRAPHY) he = launch_init_homography_multi(c0->stream, L.key, A.d + off_tab[0], map, first, L.grid);
-                else if (L.kernel == MERGE_EXTRINSICS) he = launch_init_extrinsics_multi(c0->stream, L.key, A.d + off_tab[1], map, first, L.grid, L.dyn);
-                else he = launch_lm_trial_multi(c0->stream, L.key, A.d + off_tab[2], map, first, nblk, L.grid, L.k, L.first, L.final_only);
-                if (he != hipSuccess) break;
-            }
-            if (dbg) fprintf(stderr, "[ccal] fit_many merged: %d contexts, %zu launches, %zu table bytes; recording %.1f us, merge + launches %.1f us\n", m,
-                             launches.size(), bytes, 1e6 * (t_rec1 - t_rec0), 1e6 * (now_s() - t_rec1));
-            if (he == hipSuccess) he = hipEventRecord(A.ev, c0->stream);
-            for (int e = 1; e < m && he == hipSuccess; e++)
-                if (ctxs[idx[e]]->stream != c0->stream) he = hipStreamWaitEvent(ctxs[idx[e]]->stream, A.ev, 0);
-            if (he != hipSuccess) {
-                (void)hipStreamSynchronize(c0->stream);
-                for (int e = 0; e < m; e++) {
-                    merge_poison(ctxs[idx[e]]);
-                    ph[idx[e]] = FitPhase();
-                    ph[idx[e]].rc = fail(CCAL_E_DEVICE, std::string("ccal_fit_many: merged launch failed: ") + hipGetErrorString(he));
-                    ph[idx[e]].err = g_err;
-                }
-            }
-            return true;
+        hipError_t he = hipMemcpyAsync(A.d, A.h, bytes, hipMemcpyHostToDevice, c0->stream);
+        for (auto &L : launches) {
+            if (he != hipSuccess) break;
+            const int *map = reinterpret_cast<const int *>(A.d + L.off_map), *first = reinterpret_cast<const int *>(A.d + L.off_first),
+                      *nblk = reinterpret_cast<const int *>(A.d + L.off_nblk);
+            if (L.kernel == MERGE_HOMOGRAPHY) he = launch_init_homography_multi(c0->stream, L.key, A.d + off_tab[MERGE_HOMOGRAPHY], map, first, L.grid);
+            else if (L.kernel == MERGE_EXTRINSICS) he = launch_init_extrinsics_multi(c0->stream, L.key, A.d + off_tab[MERGE_EXTRINSICS], map, first, L.grid, L.dyn);
+            else he = launch_lm_trial_multi(c0->stream, L.key, A.d + off_tab[MERGE_LM], map, first, nblk, L.grid, L.k, L.first, L.final_only);
         }
+        if (he == hipSuccess) he = hipEventRecord(A.ev, c0->stream);
+        n_launches += launches.size();
+        return he;
+    };
+    auto fail_all = [&](hipError_t he) {
+        (void)hipStreamSynchronize(c0->stream);
+        for (int e = 0; e < m; e++) {
+            merge_poison(ctxs[idx[e]]);
+            ph[idx[e]] = FitPhase();
+            ph[idx[e]].rc = fail(CCAL_E_DEVICE, std::string("ccal_fit_many: merged launch failed: ") + hipGetErrorString(he));
+            ph[idx[e]].err = g_err;
+        }
+    };
+
+    // ---- step 1: the two initialisation stages of every context
+    const double t0 = now_s();
+    bool ok = hipSetDevice(c0->device) == hipSuccess;
+    for (int e = 0; e < m; e++) {
+        ccal_ctx *c = ctxs[idx[e]];
+        merge_recorder() = &rec[e];
+        c->recording = true;
+        fit_begin_init(c, ph[idx[e]]);
+        c->recording = false;
+        merge_recorder() = nullptr;
+        if (rec[e].unsupported || ph[idx[e]].rc < 0 || rec[e].recs.size() != 2 || rec[e].recs[0].kernel != MERGE_HOMOGRAPHY ||
+            rec[e].recs[1].kernel != MERGE_EXTRINSICS)
+            ok = false;
     }
-    for (int e = 0; e < m; e++) merge_poison(ctxs[idx[e]]);     // nothing was launched: the ordinary path starts every one of them afresh
-    return false;
+    if (!ok) {
+        for (int e = 0; e < m; e++) merge_poison(ctxs[idx[e]]);     // nothing was launched: the ordinary path starts every one of them afresh
+        return false;
+    }
+    size_t n_launches = 0;
+    static const bool one_step = getenv("CCAL_MERGE_ONE_STEP") != nullptr;     // (experiments: everything recorded before anything is launched)
+    hipError_t he = one_step ? hipSuccess : merge_and_launch(t_arena[0], 0, 2, {MERGE_HOMOGRAPHY, MERGE_EXTRINSICS}, n_launches);
+    // (from here on launches are in flight: a failure is a HIP error and fails the contexts, it cannot fall back)
+    if (he != hipSuccess) { fail_all(he); return true; }
+    const double t1 = now_s();
+    // ---- step 2: the solves, recorded while the initialisation runs
+    size_t len = 0;
+    for (int e = 0; e < m; e++) {
+        ccal_ctx *c = ctxs[idx[e]];
+        merge_recorder() = &rec[e];
+        c->recording = true;
+        fit_begin_lm(c, ph[idx[e]]);
+        c->recording = false;
+        merge_recorder() = nullptr;
+        bool good = !rec[e].unsupported && ph[idx[e]].lm_begun && rec[e].recs.size() >= 3;
+        for (size_t j = 2; j < rec[e].recs.size(); j++) good = good && rec[e].recs[j].kernel == MERGE_LM;
+        if (!good) {
+            // (cannot happen for a context merge_ok has passed; if it does, the context fails alone: its solve is not launched)
+            rec[e].recs.resize(2);
+            merge_poison(c);
+            if (ph[idx[e]].rc >= 0 && ph[idx[e]].lm_rc >= 0) { ph[idx[e]].lm_rc = fail(CCAL_E_STATE, "ccal_fit_many: the solve has no merged form"); ph[idx[e]].err = g_err; }
+            ph[idx[e]].lm_begun = false;
+        }
+        len = std::max(len, rec[e].recs.size());
+    }
+    if (one_step && (he = merge_and_launch(t_arena[0], 0, 2, {MERGE_HOMOGRAPHY, MERGE_EXTRINSICS}, n_launches)) != hipSuccess) { fail_all(he); return true; }
+    if (len > 2) he = merge_and_launch(t_arena[1], 2, len, {MERGE_LM}, n_launches);
+    for (int e = 1; e < m && he == hipSuccess; e++)
+        if (ctxs[idx[e]]->stream != c0->stream) he = hipStreamWaitEvent(ctxs[idx[e]]->stream, t_arena[1].ev ? t_arena[1].ev : t_arena[0].ev, 0);
+    if (dbg) fprintf(stderr, "[ccal] fit_many merged: %d contexts, %zu launches; initialisation recorded + launched in %.1f us, solves in %.1f us\n", m,
+                     n_launches, 1e6 * (t1 - t0), 1e6 * (now_s() - t1));
+    if (he != hipSuccess) fail_all(he);
+    return true;
 }
 
 int ccal_fit_many(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out) {
