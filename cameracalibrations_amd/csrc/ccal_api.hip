@@ -1650,17 +1650,25 @@ int ccal_calibrate_many(const float *obj, int32_t P, int32_t n, const float *con
     std::vector<ccal_ctx *> live;
     std::vector<int> live_i;
     static const bool no_small = getenv("CCAL_NO_SMALL_CALL") != nullptr;
+    auto is_small = [&](int i) {
+        return P >= 1 && N[i] >= 1 && sizeof(float) * 3 * (size_t)P <= PIN_OBJ_BYTES && sizeof(float) * 2 * (size_t)P * N[i] <= PIN_IMG_BYTES &&
+               sizeof(double) * 8 * (size_t)N[i] <= PIN_POSE_BYTES && !no_small;
+    };
+    // four or more small calibrations will share merged launches: they are staged on the one stream those run on, and one kernel
+    // copies all of them; fewer keep their own streams (their pipelines overlap there) and their own copy launches
+    int n_small = 0;
+    for (int i = 0; i < n; i++) n_small += (img[i] && out[i] && is_small(i)) ? 1 : 0;
+    const bool share = n_small >= 4;
     for (int i = 0; i < n; i++) {
         ccal_ctx *c = pool[i];
         if (!img[i] || !out[i] || N[i] < 1) { st[i] = fail(CCAL_E_ARG, "ccal_calibrate_many: NULL / empty calibration"); errs[i] = g_err; continue; }
-        c->small_call = P >= 1 && sizeof(float) * 3 * (size_t)P <= PIN_OBJ_BYTES && sizeof(float) * 2 * (size_t)P * N[i] <= PIN_IMG_BYTES &&
-                        sizeof(double) * 8 * (size_t)N[i] <= PIN_POSE_BYTES && !no_small;
+        c->small_call = is_small(i);
         c->host_poses = c->small_call ? reinterpret_cast<double *>(static_cast<char *>(c->h_pin) + PIN_POSE_OFF) : nullptr;
         // small inputs: staged and copied on the one stream the merged launches will run on, nothing waited for; larger ones: their own
         // stream, uploaded before this loop goes on (the merged launches would not wait for another stream's copies)
-        c->stream = c->small_call ? shared : c->own_stream;
+        c->stream = (c->small_call && share) ? shared : c->own_stream;
         c->defer_sync = c->small_call;
-        c->defer_copy = c->small_call ? t_segs + n_segs : nullptr;     // (one copy launch for all of them, below)
+        c->defer_copy = (c->small_call && share) ? t_segs + n_segs : nullptr;     // (one copy launch for all of them, below)
         int rc = ccal_set_problem(c, obj, P, N[i], width, height, aspect, flags, max_iter, eps);
         if (rc >= 0 && (rc = ccal_set_image_points(c, img[i])) < 0) { c->have_problem = false; c->obj_staged = 0; }
         c->defer_sync = false;
