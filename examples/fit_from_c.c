@@ -43,7 +43,30 @@ int main(int argc, char **argv) {
     for (int32_t i = 0; i < N; i++)
         printf("R %.17g %.17g %.17g t %.17g %.17g %.17g\n", rvecs[3 * i], rvecs[3 * i + 1], rvecs[3 * i + 2], tvecs[3 * i],
                tvecs[3 * i + 1], tvecs[3 * i + 2]);
+    /* the batched form of the same seam: five calibrations in one call (here: the same corners five times; in a caller's hands
+     * one set per camera) -- small fits share merged launches on the device; every result must equal the single call's */
+    enum { NCAL = 5 };
+    const float *imgs[NCAL];
+    int32_t Ns[NCAL], status[NCAL];
+    double *outs[NCAL];
+    for (int c = 0; c < NCAL; c++) {
+        imgs[c] = img;
+        Ns[c] = N;
+        outs[c] = malloc(sizeof(double) * (11 + 6 * (size_t)N));
+        if (!outs[c]) return 2;
+    }
+    const int rcm = ccal_calibrate_many(obj, P, NCAL, imgs, Ns, width, height, aspect, flags, 30, 1e-3, 0, outs, status);
+    if (rcm < 0) { fprintf(stderr, "ccal_calibrate_many: %d: %s\n", rcm, ccal_last_error()); return 1; }
+    int same = 1;
+    for (int c = 0; c < NCAL; c++) {
+        const double *o = outs[c];
+        same = same && status[c] == rc && o[0] == K4[0] && o[1] == K4[1] && o[2] == K4[2] && o[3] == K4[3] && o[4] == dist5[0] &&
+               o[9] == rms && (int32_t)o[10] == iters;
+        for (int32_t i = 0; i < 3 * N; i++) same = same && o[11 + i] == rvecs[i] && o[11 + 3 * (size_t)N + i] == tvecs[i];
+        free(outs[c]);
+    }
+    printf("calibrate_many %d calibrations identical %d\n", (int)NCAL, same);
     ccal_thread_cleanup();
     free(obj); free(img); free(rvecs); free(tvecs);
-    return 0;
+    return same ? 0 : 1;
 }

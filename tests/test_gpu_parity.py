@@ -649,6 +649,8 @@ def test_c_abi_from_plain_c(golden_dir, tmp_path):
     assert (vals["frow"], vals["fcol"], vals["crow"], vals["ccol"], vals["k"]) == (m.frow, m.fcol, m.crow, m.ccol, m.k)
     poses = np.array([[float(x) for x in ln.split()[1:4] + ln.split()[5:8]] for ln in out[2:2 + img.shape[0]]])
     assert np.array_equal(poses[:, :3], np.array(m.Rs)) and np.array_equal(poses[:, 3:], np.array(m.ts))
+    # ... and the batched call from C (ccal_calibrate_many, five calibrations: merged launches) returns the same five times
+    assert out[2 + img.shape[0]].strip() == "calibrate_many 5 calibrations identical 1"
 
 
 RANDOM_CASES = [
