@@ -260,6 +260,22 @@ def detect_block(with_cpu=True, reps=10):
         ts.append(time.perf_counter() - t0)
     out["images_per_s"] = len(cases) / float(np.median(ts))
     out["pixels_per_s"] = out["pixels"] / float(np.median(ts))
+    # the six example images as one calibration's images: image-by-image calls against one ccal_detect_corners_many (three in flight)
+    from cameracalibrations_amd.detect import detect_corners_many
+    six = [im for im, _, _ in cases[:6]]
+    a = [detect_corners(im, nc) for im in six]
+    b = detect_corners_many(six, nc)
+    t1, t2 = [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for im in six:
+            detect_corners(im, nc)
+        t1.append(time.perf_counter() - t0)
+        t0 = time.perf_counter()
+        detect_corners_many(six, nc)
+        t2.append(time.perf_counter() - t0)
+    out["example_images"] = {"images": 6, "us_per_image_one_at_a_time": 1e6 * float(np.median(t1)) / 6, "us_per_image_three_in_flight": 1e6 * float(np.median(t2)) / 6,
+                             "identical": bool(all(np.array_equal(x, y) for x, y in zip(a, b)))}
     if with_cpu:
         from oracle import detect_oracle as D      # (the CPU comparison only)
         t0 = time.perf_counter()

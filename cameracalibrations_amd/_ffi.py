@@ -111,6 +111,8 @@ SIGNATURES = {
                                      C.c_int32, C.c_double, C.c_void_p]),
     "ccal_detect_corners": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
                                       C.c_int32, _dp, C.POINTER(C.c_int32), _dp]),
+    "ccal_detect_corners_many": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64, C.c_int32,
+                                           C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]),
     "ccal_debug_image_grams": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "ccal_debug_acc_sum": (C.c_int, [C.c_void_p, _dp, C.c_int32, C.c_int32, _dp]),
     "ccal_debug_get_homographies": (C.c_int, [C.c_void_p, _dp]),

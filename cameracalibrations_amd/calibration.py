@@ -230,6 +230,7 @@ def fit(files, n_corners, checker_size, aspect=1, with_distortion=True, inverse_
     (src/buildcalibrations.jl:12-26).  `detector(file, n_corners) -> (P,2) corners or None`
     overrides the built-in device detector that stands in for `_detect_corners`
     (src/detect_fit.jl:5-21)."""
+    builtin = detector is None
     if detector is None:
         from .detect import detect_corners, load_gray      # device detector (csrc/ccal_detect.hip)
         cache = {}
@@ -245,7 +246,15 @@ def fit(files, n_corners, checker_size, aspect=1, with_distortion=True, inverse_
         if f not in seen:
             seen.add(f)
             uniq.append(f)
-    found = [(f, detector(f, n_corners)) for f in uniq]
+    found = None
+    if builtin:                                          # the calibration's images in one call: three in flight on the device
+        from .detect import detect_corners_many, load_gray
+        grays = [load_gray(f) for f in uniq]
+        if len({g.shape for g in grays}) == 1:
+            cs = detect_corners_many(grays, n_corners)
+            found = [(f, None if c is None else c.transpose(1, 0, 2).reshape(-1, 2)) for f, c in zip(uniq, cs)]
+    if found is None:
+        found = [(f, detector(f, n_corners)) for f in uniq]
     found = [(f, m) for f, m in found if m is not None]  # skipmissing, src/detect_fit.jl:65
     if sz is None:
         raise ValueError("sz (size of the first image, (rows, cols)) is required")

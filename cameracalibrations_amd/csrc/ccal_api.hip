@@ -113,6 +113,9 @@ struct ccal_ctx {
     int p2p_mode = 0;                  // ccal_p2p_set_exchange: 0 automatic, 1 one-workgroup exchange, 2 fused whatever was detected
     bool p2p_split = false;            // shards of one host thread share this GPU AND its stream: send / receive as two kernels
     Detector *detector = nullptr;      // corner detector buffers (ccal_detect_corners)
+    static constexpr int DET_SLOTS = 3; // ccal_detect_corners_many: images in flight, each with a detector and a stream of its own
+    Detector *det_slot[DET_SLOTS] = {nullptr, nullptr, nullptr};
+    hipStream_t det_stream[DET_SLOTS] = {nullptr, nullptr, nullptr};
     int64_t n_global = 0;
     int lm_batch = 8;
     // optional per-sweep event timing
@@ -271,6 +274,8 @@ void ccal_destroy(ccal_ctx *c) {
     delete c->comm;
     delete c->p2p;
     delete c->detector;
+    for (auto &d : c->det_slot) delete d;
+    for (auto &st : c->det_stream) if (st) (void)hipStreamDestroy(st);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -2112,6 +2117,40 @@ int ccal_detect_corners(ccal_ctx *c, const uint8_t *gray, int32_t rows, int32_t 
     if (rc == -1) return fail(CCAL_E_ARG, "ccal_detect_corners: " + err);
     if (rc < 0) return fail(CCAL_E_DEVICE, err);
     *found = f;
+    return CCAL_OK;
+}
+
+// The images of one calibration (one size), three in flight: while the device works on image t the host sorts the peaks of image
+// t - 1 and launches its refinement, and runs the lattice search of image t - 2 -- each slot has a detector (buffers, pinned block)
+// and a stream of its own.  Same arithmetic per image as ccal_detect_corners: same corners.
+int ccal_detect_corners_many(ccal_ctx *c, const uint8_t *const *gray, int32_t n, int32_t rows, int32_t cols, int64_t stride_row,
+                             int64_t stride_col, int32_t n1, int32_t n2, double *const *corners, int32_t *found) {
+    if (!c || n < 0 || (n > 0 && (!gray || !corners || !found))) return fail(CCAL_E_ARG, "ccal_detect_corners_many: NULL argument");
+    if (rows < 32 || cols < 32 || n1 < 2 || n2 < 2 || (int64_t)n1 * n2 > Detector::MAX_PEAKS)
+        return fail(CCAL_E_ARG, "ccal_detect_corners_many: bad image or board size");
+    for (int i = 0; i < n; i++)
+        if (!gray[i] || !corners[i]) return fail(CCAL_E_ARG, "ccal_detect_corners_many: NULL image / output");
+    HIPCHK(hipSetDevice(c->device));
+    constexpr int S = ccal_ctx::DET_SLOTS;
+    for (int k = 0; k < S; k++) {
+        if (!c->det_slot[k]) c->det_slot[k] = new Detector();
+        if (!c->det_stream[k]) HIPCHK(hipStreamCreateWithFlags(&c->det_stream[k], hipStreamNonBlocking));
+    }
+    std::string err;
+    int rc = 0;
+    for (int t = 0; t < n + 2 && rc == 0; t++) {
+        if (t < n) rc = c->det_slot[t % S]->begin(c->det_stream[t % S], gray[t], rows, cols, stride_row, stride_col, err);
+        if (rc == 0 && t >= 1 && t - 1 < n) rc = c->det_slot[(t - 1) % S]->mid(c->det_stream[(t - 1) % S], n1, n2, nullptr, err);
+        if (rc == 0 && t >= 2) {
+            int f = 0;
+            rc = c->det_slot[(t - 2) % S]->end(c->det_stream[(t - 2) % S], n1, n2, corners[t - 2], &f, err);
+            found[t - 2] = f;
+        }
+    }
+    if (rc != 0) {
+        for (int k = 0; k < S; k++) (void)hipStreamSynchronize(c->det_stream[k]);     // nothing of this call stays in flight
+        return rc == -1 ? fail(CCAL_E_ARG, "ccal_detect_corners_many: " + err) : fail(CCAL_E_DEVICE, err);
+    }
     return CCAL_OK;
 }
 

@@ -451,7 +451,7 @@ bool order_grid(const std::vector<P2> &pts, const std::vector<double> &resp, int
 }
 }  // namespace
 
-Detector::~Detector() { release(); }
+Detector::~Detector() { release(); delete static_cast<std::vector<Peak> *>(cur_peaks); }
 
 void Detector::release() {
     (void)hipFree(d_raw); (void)hipFree(d_img); (void)hipFree(d_tmp); (void)hipFree(d_g); (void)hipFree(d_R);
@@ -484,12 +484,15 @@ int Detector::wait_flag(hipStream_t stream, unsigned long long want, std::string
     return 0;
 }
 
-int Detector::detect(hipStream_t stream, const uint8_t *gray, int rows, int cols, long long sr, long long sc, int n1,
-                     int n2, double *corners, int *found, double *stage_out, std::string &err) {
-    *found = 0;
+namespace {
+constexpr size_t PIN_COUNT = 64, PIN_PEAKS = 128, PIN_SUB = PIN_PEAKS + sizeof(Peak) * Detector::MAX_PEAKS,
+                 PIN_IMG = PIN_SUB + sizeof(double) * 2 * Detector::MAX_PEAKS;
+}
+
+int Detector::begin(hipStream_t stream, const uint8_t *gray, int rows, int cols, long long sr, long long sc, std::string &err) {
     const size_t px = (size_t)rows * cols;
-    constexpr size_t PIN_COUNT = 64, PIN_PEAKS = 128, PIN_SUB = PIN_PEAKS + sizeof(Peak) * MAX_PEAKS,
-                     PIN_IMG = PIN_SUB + sizeof(double) * 2 * MAX_PEAKS;
+    cur_gray = gray; cur_rows = rows; cur_cols = cols; cur_sr = sr; cur_sc = sc; cur_n = 0; cur_refining = false;
+    if (!cur_peaks) cur_peaks = new std::vector<Peak>();
     if (px > cap_px) {
         release();
         DCHK(hipMalloc(&d_raw, px));
@@ -509,7 +512,6 @@ int Detector::detect(hipStream_t stream, const uint8_t *gray, int rows, int cols
     unsigned long long *h_flag = reinterpret_cast<unsigned long long *>(h_pin);
     int *h_count = reinterpret_cast<int *>(h_pin + PIN_COUNT);
     Peak *h_peaks = reinterpret_cast<Peak *>(h_pin + PIN_PEAKS);
-    double *h_sub = reinterpret_cast<double *>(h_pin + PIN_SUB);
     // the caller's layout is uploaded as is: bytes span the strided extent (through the pinned block: a plain DMA)
     const long long span = (long long)(rows - 1) * sr + (long long)(cols - 1) * sc + 1;
     if (span > (long long)px || sr < 1 || sc < 1) { err = "image strides must describe a dense rows x cols matrix"; return -1; }
@@ -527,6 +529,15 @@ int Detector::detect(hipStream_t stream, const uint8_t *gray, int rows, int cols
     hipLaunchKernelGGL(k_det_export, dim3(1), dim3(256), 0, stream, (const Peak *)d_list, (const int *)count, MAX_PEAKS, h_count,
                        h_peaks, h_flag, ++pin_seq);
     DCHK(hipGetLastError());
+    return 0;
+}
+
+int Detector::mid(hipStream_t stream, int n1, int n2, double *stage_out, std::string &err) {
+    const size_t px = (size_t)cur_rows * cur_cols;
+    unsigned long long *h_flag = reinterpret_cast<unsigned long long *>(h_pin);
+    int *h_count = reinterpret_cast<int *>(h_pin + PIN_COUNT);
+    Peak *h_peaks = reinterpret_cast<Peak *>(h_pin + PIN_PEAKS);
+    double *h_sub = reinterpret_cast<double *>(h_pin + PIN_SUB);
     int rc = wait_flag(stream, pin_seq, err);
     if (rc) return rc;
     int n = *h_count;
@@ -535,16 +546,29 @@ int Detector::detect(hipStream_t stream, const uint8_t *gray, int rows, int cols
         DCHK(hipMemcpy(stage_out + px, d_R, px * 8, hipMemcpyDeviceToHost));
     }
     if (n > MAX_PEAKS) n = MAX_PEAKS;
-    if (n < n1 * n2) return 0;
-    std::vector<Peak> peaks(h_peaks, h_peaks + n);
+    cur_n = n;
+    if (n < n1 * n2) return 0;       // (too few peaks for a board: end() reports "not found")
+    std::vector<Peak> &peaks = *static_cast<std::vector<Peak> *>(cur_peaks);
+    peaks.assign(h_peaks, h_peaks + n);
     std::sort(peaks.begin(), peaks.end(), [&](const Peak &x, const Peak &y) { return x.r != y.r ? x.r < y.r : x.c < y.c; });
     // raster order; the sub-pixel kernel reads the list from, and writes the refined corners to, the pinned block
     memcpy(h_peaks, peaks.data(), sizeof(Peak) * n);
-    hipLaunchKernelGGL(k_det_subpix, dim3(n), dim3(64), 0, stream, (const double *)d_img, rows, cols, (const Peak *)h_peaks, n, h_sub,
+    hipLaunchKernelGGL(k_det_subpix, dim3(n), dim3(64), 0, stream, (const double *)d_img, cur_rows, cur_cols, (const Peak *)h_peaks, n, h_sub,
                        reinterpret_cast<unsigned int *>(d_misc) + 8, h_flag, ++pin_seq);
     DCHK(hipGetLastError());
-    rc = wait_flag(stream, pin_seq, err);
+    cur_refining = true;
+    return 0;
+}
+
+int Detector::end(hipStream_t stream, int n1, int n2, double *corners, int *found, std::string &err) {
+    *found = 0;
+    if (!cur_refining) return 0;
+    cur_refining = false;
+    const int n = cur_n;
+    double *h_sub = reinterpret_cast<double *>(h_pin + PIN_SUB);
+    const int rc = wait_flag(stream, pin_seq, err);
     if (rc) return rc;
+    const std::vector<Peak> &peaks = *static_cast<std::vector<Peak> *>(cur_peaks);
     std::vector<double> sub(h_sub, h_sub + 2 * (size_t)n);
     // merge peaks that converged onto the same corner (strongest first), keep raster order
     std::vector<int> order(n), keep;
@@ -560,8 +584,17 @@ int Detector::detect(hipStream_t stream, const uint8_t *gray, int rows, int cols
     std::vector<P2> pts;
     std::vector<double> resp;
     for (int k : keep) { pts.push_back({sub[2 * k], sub[2 * k + 1]}); resp.push_back(peaks[k].v); }
-    if (order_grid(pts, resp, n1, n2, gray, sr, sc, rows, cols, corners)) *found = 1;
+    if (order_grid(pts, resp, n1, n2, cur_gray, cur_sr, cur_sc, cur_rows, cur_cols, corners)) *found = 1;
     return 0;
+}
+
+int Detector::detect(hipStream_t stream, const uint8_t *gray, int rows, int cols, long long sr, long long sc, int n1,
+                     int n2, double *corners, int *found, double *stage_out, std::string &err) {
+    *found = 0;
+    int rc = begin(stream, gray, rows, cols, sr, sc, err);
+    if (rc == 0) rc = mid(stream, n1, n2, stage_out, err);
+    if (rc == 0) rc = end(stream, n1, n2, corners, found, err);
+    return rc;
 }
 
 }  // namespace ccal

@@ -20,7 +20,21 @@ class Detector {
     int detect(hipStream_t stream, const uint8_t *gray, int rows, int cols, long long sr, long long sc, int n1, int n2,
                double *corners, int *found, double *stage_out, std::string &err);
 
+    // The same in three steps, so that a caller can keep several images in flight (one Detector and one stream per image slot:
+    // ccal_detect_corners_many): begin = upload + the image-wide kernels up to the peak list (nothing waited for);
+    // mid = wait for the peak list, sort it, launch the sub-pixel refinement; end = wait for it, merge, lattice, ordering.
+    // `gray` must stay valid until end() has returned.  detect() = begin + mid + end.
+    int begin(hipStream_t stream, const uint8_t *gray, int rows, int cols, long long sr, long long sc, std::string &err);
+    int mid(hipStream_t stream, int n1, int n2, double *stage_out, std::string &err);
+    int end(hipStream_t stream, int n1, int n2, double *corners, int *found, std::string &err);
+
   private:
+    // between the steps of one image
+    const uint8_t *cur_gray = nullptr;
+    int cur_rows = 0, cur_cols = 0, cur_n = 0;
+    long long cur_sr = 0, cur_sc = 0;
+    bool cur_refining = false;
+    void *cur_peaks = nullptr;     // std::vector<Peak> of the image in flight (opaque here: Peak lives in the .hip)
     void release();
     uint8_t *d_raw = nullptr;
     double *d_img = nullptr, *d_tmp = nullptr, *d_g = nullptr, *d_R = nullptr, *d_out = nullptr, *d_taps = nullptr;

@@ -34,6 +34,28 @@ def detect_corners(img, n_corners, solver=None, stages=False):
     return (res, stage) if stages else res
 
 
+def detect_corners_many(imgs, n_corners, solver=None):
+    """`detect_corners` for the images of one calibration (2-D uint8 arrays of one shape): one call of ccal_detect_corners_many, which
+    keeps three images in flight (the host's share of an image overlaps the device's share of the next).  -> list of (n1, n2, 2)
+    corner arrays / None, the same values `detect_corners` returns for each image."""
+    from .calibration import _shared_solver
+    s = solver or _shared_solver(0)
+    imgs = [np.ascontiguousarray(im) for im in imgs]
+    if not imgs:
+        return []
+    rows, cols = imgs[0].shape
+    for im in imgs:
+        if im.dtype != np.uint8 or im.ndim != 2 or im.shape != (rows, cols):
+            raise TypeError("expected 2-D uint8 gray images of one shape")
+    n, P = len(imgs), int(n_corners[0]) * int(n_corners[1])
+    outs = [np.zeros((P, 2)) for _ in imgs]
+    found = (C.c_int32 * n)()
+    ip = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+    op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    F.check(F.lib().ccal_detect_corners_many(s._h, ip, n, rows, cols, cols, 1, int(n_corners[0]), int(n_corners[1]), op, found))
+    return [o.reshape(int(n_corners[1]), int(n_corners[0]), 2).transpose(1, 0, 2) if f else None for o, f in zip(outs, found)]
+
+
 def load_gray(file):
     """FileIO.load + Gray + rawview (src/detect_fit.jl:6-7): 8-bit gray matrix (rows, cols)."""
     from PIL import Image

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CCAL_VERSION 104 /* 0.1.4: ccal_fit_many, ccal_calibrate_many; 0.1.3: ccal_stats.sweep_form (was padding); 0.1.2: ccal_p2p_export2 / ccal_p2p_connect2, ccal_p2p_set_exchange mode 2 */
+#define CCAL_VERSION 104 /* 0.1.4: ccal_fit_many, ccal_calibrate_many, ccal_detect_corners_many; 0.1.3: ccal_stats.sweep_form (was padding); 0.1.2: ccal_p2p_export2 / ccal_p2p_connect2, ccal_p2p_set_exchange mode 2 */
 
 /* status codes */
 #define CCAL_OK            0
@@ -305,6 +305,12 @@ int  ccal_rectify_image(ccal_ctx *ctx, const uint8_t *img, int32_t rows, int32_t
 int  ccal_detect_corners(ccal_ctx *ctx, const uint8_t *gray, int32_t rows, int32_t cols, int64_t stride_row,
                          int64_t stride_col, int32_t n1, int32_t n2, double *corners, int32_t *found,
                          double *stage_out);
+
+/* The same for the n images of one calibration (one size, one layout): three images are kept in flight, so that the host's share
+ * of an image (staging, peak sort, lattice search) overlaps the device's share of the next ones.  corners[i] [2, n1*n2],
+ * found[i] as above; the same corners as n calls of ccal_detect_corners.  The images must stay valid until the call returns. */
+int  ccal_detect_corners_many(ccal_ctx *ctx, const uint8_t *const *gray, int32_t n, int32_t rows, int32_t cols, int64_t stride_row,
+                              int64_t stride_col, int32_t n1, int32_t n2, double *const *corners, int32_t *found);
 
 /* ---- diagnostics (stage-wise parity tests; not part of the reference surface) -------- */
 /* per-image 16x16 Gram matrices [Je|Ji|e]^T[Je|Ji|e] at the given point -> G [256,N] host */

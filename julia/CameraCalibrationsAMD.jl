@@ -166,6 +166,20 @@ function detect_corners(c::Context, gray::Matrix{UInt8}, n_corners)
     return reshape([(corners[1, i], corners[2, i]) for i in 1:n1*n2], n1, n2)
 end
 
+# the images of one calibration (one size) in one call: three in flight on the device (include/ccal.h ccal_detect_corners_many)
+function detect_corners_many(c::Context, grays::Vector{Matrix{UInt8}}, n_corners)
+    isempty(grays) && return []
+    rows, cols = size(grays[1]); n1, n2 = n_corners
+    outs = [zeros(Float64, 2, n1 * n2) for _ in grays]; found = zeros(Int32, length(grays))
+    GC.@preserve grays outs begin
+        ip = Ptr{Cvoid}[pointer(g) for g in grays]; op = Ptr{Cvoid}[pointer(o) for o in outs]
+        check(ccall((:ccal_detect_corners_many, LIB), Int32,
+                    (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Int32, Int32, Int32, Int64, Int64, Int32, Int32, Ptr{Ptr{Cvoid}}, Ptr{Int32}),
+                    c.h, ip, length(grays), rows, cols, 1, rows, n1, n2, op, found))
+    end
+    return [f == 0 ? missing : reshape([(o[1, i], o[2, i]) for i in 1:n1*n2], n1, n2) for (o, f) in zip(outs, found)]
+end
+
 # ---- many-image maps: image n through pose n, one call (include/ccal.h ccal_project_many / ccal_unproject_many) ----
 function project_many(c::Context, xyz::Array{Float64}, f, cc, k, rvecs::Matrix{Float64}, tvecs::Matrix{Float64}, checker_size)
     N = size(rvecs, 2); per_image = ndims(xyz) == 3; M = size(xyz, 2); out = zeros(Float64, 2, M, N)

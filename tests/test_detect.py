@@ -149,3 +149,35 @@ def test_gpu_detection_threaded():
         threaded = list(pool.map(lambda im: detect_corners(im, nc), imgs * 4))
     for k, res in enumerate(threaded):
         assert np.array_equal(res, serial[k % len(imgs)])
+
+
+@pytest.mark.gpu
+def test_gpu_detection_of_many_images_in_flight():
+    """ccal_detect_corners_many keeps three images of a calibration in flight (detector, pinned block and stream per slot): the same
+    corners as image-by-image calls, for the reference's six example images (several times over, a blank and a noise image among them:
+    `missing` stays `missing`), for one image, for none; images of different shapes are refused."""
+    from cameracalibrations_amd.detect import detect_corners, detect_corners_many
+    ex, imgs = _example()
+    nc = tuple(ex["n_corners"])
+    blank = np.full_like(imgs[0], 128)
+    noise = np.random.default_rng(1).integers(0, 256, imgs[0].shape, dtype=np.uint8)
+    batch = imgs + [blank] + imgs[::-1] + [noise] + imgs[:1] + [blank, blank] + imgs[2:4]
+    one = [detect_corners(im, nc) for im in batch]
+    for rep in range(3):
+        many = detect_corners_many(batch, nc)
+        assert len(many) == len(batch)
+        for a, b in zip(one, many):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert np.array_equal(a, b)
+    assert sum(m is None for m in many) == 4
+    assert detect_corners_many([], nc) == []
+    assert np.array_equal(detect_corners_many(imgs[:1], nc)[0], one[0])
+    assert np.array_equal(detect_corners_many(imgs[:2], nc)[1], one[1])
+    with pytest.raises(TypeError):
+        detect_corners_many([imgs[0], imgs[1][:-8]], nc)
+    # other board sizes on the same context afterwards (buffers are per slot)
+    xys, img = syn.generate_checkerboard((13, 14), 97)
+    res = detect_corners_many([img.astype(np.uint8)] * 4, (13, 14))
+    for r in res:
+        assert r is not None and np.linalg.norm(r.transpose(1, 0, 2).reshape(-1, 2) - xys, axis=1).max() < 1
