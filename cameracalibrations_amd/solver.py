@@ -321,23 +321,38 @@ def fit_many(solvers, check=True):
 
 def fit_models(sz, objpoints, imgpointsss, n_corners, with_distortion, aspect, device=0):
     """`fit_model` (src/detect_fit.jl:27-61) for several calibrations at once -- the loop a caller with many cameras runs around
-    src/buildcalibrations.jl:12-26: imgpointsss = one list / array of per-image corners PER calibration (the template, image size,
-    flags and aspect are shared, as one caller's are).  One call of ccal_calibrate_many: host arrays in and out, the library's own
+    src/buildcalibrations.jl:12-26: imgpointsss = one list / array of per-image corners PER calibration, or one array
+    [calibration, image, corner, 2] when all have the same number of images (the template, image size, flags and aspect are shared, as
+    one caller's are).  One call of ccal_calibrate_many: host arrays in and out, the library's own
     pool of contexts, the fits through ccal_fit_many (small ones share merged launches).  Returns a list of fit_model's namespaces,
     the same values fit_model returns for each set on its own."""
     P = int(n_corners[0]) * int(n_corners[1])
     obj = np.ascontiguousarray(objpoints, dtype=np.float32).reshape(P, 3)
-    imgs = []
-    for pts in imgpointsss:
-        try:
-            imgs.append(np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, P, 2))
-        except ValueError:
-            imgs.append(np.stack([np.asarray(m, dtype=np.float32).reshape(P, 2) for m in pts]))
+    stacked = None
+    if isinstance(imgpointsss, np.ndarray) and imgpointsss.ndim >= 3:     # one array of all calibrations (the same number of images each)
+        stacked = np.ascontiguousarray(imgpointsss, dtype=np.float32).reshape(imgpointsss.shape[0], -1, P, 2)
+        imgs = list(stacked)
+    else:
+        imgs = []
+        for pts in imgpointsss:
+            try:
+                imgs.append(np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, P, 2))
+            except ValueError:
+                imgs.append(np.stack([np.asarray(m, dtype=np.float32).reshape(P, 2) for m in pts]))
     n = len(imgs)
-    outs = [np.zeros(11 + 6 * a.shape[0]) for a in imgs]
-    Ns = (C.c_int32 * n)(*[a.shape[0] for a in imgs])
-    ip = (C.c_void_p * n)(*[a.ctypes.data for a in imgs])
-    op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+    if stacked is not None and n > 0:                                      # ... one result block, addresses by arithmetic
+        N0 = stacked.shape[1]
+        block = np.zeros((n, 11 + 6 * N0))
+        outs = list(block)
+        Ns = (C.c_int32 * n)(*([N0] * n))
+        b_in, s_in, b_out, s_out = stacked.ctypes.data, stacked.strides[0], block.ctypes.data, block.strides[0]
+        ip = (C.c_void_p * n)(*range(b_in, b_in + n * s_in, s_in))
+        op = (C.c_void_p * n)(*range(b_out, b_out + n * s_out, s_out))
+    else:
+        outs = [np.zeros(11 + 6 * a.shape[0]) for a in imgs]
+        Ns = (C.c_int32 * n)(*[a.shape[0] for a in imgs])
+        ip = (C.c_void_p * n)(*[a.ctypes.data for a in imgs])
+        op = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
     st = (C.c_int32 * n)()
     F.check(F.lib().ccal_calibrate_many(F.f32(obj)[1], P, n, ip, Ns, int(sz[0]), int(sz[1]), float(aspect), reference_flags(with_distortion),
                                         CRITERIA[0], CRITERIA[1], int(device), op, st))

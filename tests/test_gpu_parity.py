@@ -1396,6 +1396,12 @@ def test_fit_many_equals_one_fit_at_a_time(golden_dir):
     assert fit_models(ex["image_size_wh"], obj, [], ex["n_corners"], True, 1) == []
     assert len(fit_models(ex["image_size_wh"], obj, sets[:2], ex["n_corners"], True, 1)) == 2       # (two: streams of their own)
     many = fit_models(ex["image_size_wh"], obj, sets, ex["n_corners"], True, 1)                        # (six: merged launches)
+    # one array [calibration, image, corner, 2] in: the same
+    arr = np.stack([np.stack(imgs[:4]), np.stack(imgs[2:]), np.stack(imgs[1:5]), np.stack(imgs[:4][::-1]), np.stack(imgs[:4])])
+    for a, sub in zip(fit_models(ex["image_size_wh"], obj, arr, ex["n_corners"], True, 1), arr):
+        b = fit_model(ex["image_size_wh"], obj, list(sub), ex["n_corners"], True, 1)
+        assert (a.frow, a.fcol, a.crow, a.ccol, a.k, a.rms, a.iters) == (b.frow, b.fcol, b.crow, b.ccol, b.k, b.rms, b.iters)
+        assert np.array_equal(np.array(a.Rs), np.array(b.Rs)) and np.array_equal(np.array(a.ts), np.array(b.ts))
     for sub, a in zip(sets, many):
         b = fit_model(ex["image_size_wh"], obj, sub, ex["n_corners"], True, 1)
         assert (a.frow, a.fcol, a.crow, a.ccol, a.k, a.rms, a.iters) == (b.frow, b.fcol, b.crow, b.ccol, b.k, b.rms, b.iters)

@@ -85,5 +85,12 @@ for k in ks:
         t2 = time.perf_counter()
         t_seq.append((t1 - t0) / k)
         t_many.append((t2 - t1) / k)
+    arr = np.stack([np.stack(st) for st in sets])
+    t_arr = []
+    for rep in range(a.rounds):
+        t0 = time.perf_counter()
+        fit_models(ex["image_size_wh"], obj, arr, ex["n_corners"], True, 1)
+        t_arr.append((time.perf_counter() - t0) / k)
+    print(f"[many] fit_models, one array in  calibrations {k:3d}: {1e6 * np.median(t_arr[5:]):8.1f} us per calibration", flush=True)
     print(f"[many] fit_model(s)  calibrations {k:3d}: fit_model each {1e6 * np.median(t_seq[5:]):8.1f} us per calibration | one fit_models {1e6 * np.median(t_many[5:]):8.1f} us per calibration "
           f"({np.median(t_seq[5:]) / np.median(t_many[5:]):.2f}x)", flush=True)
