@@ -160,14 +160,20 @@ __global__ __launch_bounds__(256) void k_det_peaks(const double *__restrict__ R,
 // peak count and list -> pinned host memory (one workgroup, zero-copy stores)
 __global__ __launch_bounds__(256) void k_det_export(const Peak *__restrict__ list, const int *__restrict__ count, int cap,
                                                      int *__restrict__ h_count, Peak *__restrict__ h_list,
-                                                     unsigned long long *__restrict__ h_flag, unsigned long long seq) {
+                                                     unsigned long long *__restrict__ h_flag, unsigned long long *__restrict__ d_seq) {
     const int n = min(*count, cap);
     for (int k = threadIdx.x; k < n; k += 256) h_list[k] = list[k];
     if (threadIdx.x == 0) *h_count = *count;
     __threadfence_system();
     __syncthreads();
-    // the completion word the host spins on, after every thread's stores have been made visible to it
-    if (threadIdx.x == 0) __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // the completion word the host spins on, after every thread's stores have been made visible to it.  Its value is the next number
+    // of a device-side counter the host mirrors (Detector::pin_seq): no launch argument changes from image to image, so the
+    // launches of an image can be replayed as a graph
+    if (threadIdx.x == 0) {
+        const unsigned long long seq = *d_seq + 1ull;
+        *d_seq = seq;
+        __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 __device__ __forceinline__ double bilinear(const double *__restrict__ im, int rows, int cols, double rr, double cc) {
@@ -187,7 +193,7 @@ __device__ __forceinline__ double bilinear(const double *__restrict__ im, int ro
 __global__ __launch_bounds__(64) void k_det_subpix(const double *__restrict__ im, int rows, int cols,
                                                     const Peak *__restrict__ list, int n, double *__restrict__ out,
                                                     unsigned int *__restrict__ done, unsigned long long *__restrict__ h_flag,
-                                                    unsigned long long seq) {
+                                                    unsigned long long *__restrict__ d_seq) {
     const int i = blockIdx.x, lane = threadIdx.x;
     if (i >= n) return;
     const int pri = list[i].r, pci = list[i].c;
@@ -265,7 +271,11 @@ __global__ __launch_bounds__(64) void k_det_subpix(const double *__restrict__ im
         out[2 * i] = qr; out[2 * i + 1] = qc;
         // `out` is pinned host memory: the last workgroup to finish raises the completion word the host spins on
         __threadfence_system();
-        if (atomicAdd(done, 1u) == (unsigned int)(n - 1)) __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (atomicAdd(done, 1u) == (unsigned int)(n - 1)) {
+            const unsigned long long seq = *d_seq + 1ull;          // (the last workgroup of the launch: nobody else touches the counter)
+            *d_seq = seq;
+            __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -454,6 +464,7 @@ bool order_grid(const std::vector<P2> &pts, const std::vector<double> &resp, int
 Detector::~Detector() { release(); delete static_cast<std::vector<Peak> *>(cur_peaks); }
 
 void Detector::release() {
+    if (g_begin) { (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(g_begin)); g_begin = nullptr; }
     (void)hipFree(d_raw); (void)hipFree(d_img); (void)hipFree(d_tmp); (void)hipFree(d_g); (void)hipFree(d_R);
     (void)hipFree(d_list); (void)hipFree(d_out); (void)hipFree(d_misc); (void)hipFree(d_taps);
     d_raw = nullptr; d_img = d_tmp = d_g = d_R = d_out = d_taps = nullptr; d_list = nullptr; d_misc = nullptr;
@@ -499,7 +510,9 @@ int Detector::begin(hipStream_t stream, const uint8_t *gray, int rows, int cols,
         DCHK(hipMalloc(&d_img, px * 8)); DCHK(hipMalloc(&d_tmp, px * 8)); DCHK(hipMalloc(&d_g, px * 8));
         DCHK(hipMalloc(&d_R, px * 8));
         DCHK(hipMalloc(&d_list, sizeof(Peak) * MAX_PEAKS)); DCHK(hipMalloc(&d_out, sizeof(double) * 2 * MAX_PEAKS));
-        DCHK(hipMalloc(&d_misc, 64)); DCHK(hipMalloc(&d_taps, sizeof(double) * (2 * BLUR_R + 1)));
+        DCHK(hipMalloc(&d_misc, 128)); DCHK(hipMalloc(&d_taps, sizeof(double) * (2 * BLUR_R + 1)));
+        DCHK(hipMemset(d_misc, 0, 128));
+        seq_resync = true;              // (the device-side sequence counter of the new buffer starts at the host's)
         DCHK(hipHostMalloc(reinterpret_cast<void **>(&h_pin), PIN_IMG + px, hipHostMallocMapped));
         memset(h_pin, 0, PIN_PEAKS);
         pin_img_cap = px;
@@ -516,19 +529,100 @@ int Detector::begin(hipStream_t stream, const uint8_t *gray, int rows, int cols,
     const long long span = (long long)(rows - 1) * sr + (long long)(cols - 1) * sc + 1;
     if (span > (long long)px || sr < 1 || sc < 1) { err = "image strides must describe a dense rows x cols matrix"; return -1; }
     memcpy(h_pin + PIN_IMG, gray, (size_t)span);
-    DCHK(hipMemcpyAsync(d_raw, h_pin + PIN_IMG, (size_t)span, hipMemcpyHostToDevice, stream));
-    const dim3 grid((cols + 255) / 256, rows), block(256);
-    unsigned long long *rmax = reinterpret_cast<unsigned long long *>(d_misc);
-    int *count = reinterpret_cast<int *>(d_misc) + 4;
-    hipLaunchKernelGGL(k_det_load, grid, block, 0, stream, (const uint8_t *)d_raw, sr, sc, d_img, rows, cols, rmax);
-    hipLaunchKernelGGL(k_det_blur, grid, block, 0, stream, (const double *)d_img, d_tmp, rows, cols, 0, (const double *)d_taps);
-    hipLaunchKernelGGL(k_det_blur, grid, block, 0, stream, (const double *)d_tmp, d_g, rows, cols, 1, (const double *)d_taps);
-    hipLaunchKernelGGL(k_det_chess, grid, block, 0, stream, (const double *)d_g, d_R, rows, cols, rmax);
-    hipLaunchKernelGGL(k_det_peaks, grid, block, 0, stream, (const double *)d_R, rows, cols, (const unsigned long long *)rmax,
-                       (Peak *)d_list, count, MAX_PEAKS);
-    hipLaunchKernelGGL(k_det_export, dim3(1), dim3(256), 0, stream, (const Peak *)d_list, (const int *)count, MAX_PEAKS, h_count,
-                       h_peaks, h_flag, ++pin_seq);
-    DCHK(hipGetLastError());
+    unsigned long long *d_seq = reinterpret_cast<unsigned long long *>(d_misc) + 8;
+    if (seq_resync) {
+        DCHK(hipStreamSynchronize(stream));
+        DCHK(hipMemcpy(d_seq, &pin_seq, sizeof pin_seq, hipMemcpyHostToDevice));
+        seq_resync = false;
+    }
+    auto enqueue = [&](hipStream_t st) -> hipError_t {
+        hipError_t e = hipMemcpyAsync(d_raw, h_pin + PIN_IMG, (size_t)span, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+        const dim3 grid((cols + 255) / 256, rows), block(256);
+        unsigned long long *rmax = reinterpret_cast<unsigned long long *>(d_misc);
+        int *count = reinterpret_cast<int *>(d_misc) + 4;
+        hipLaunchKernelGGL(k_det_load, grid, block, 0, st, (const uint8_t *)d_raw, sr, sc, d_img, rows, cols, rmax);
+        hipLaunchKernelGGL(k_det_blur, grid, block, 0, st, (const double *)d_img, d_tmp, rows, cols, 0, (const double *)d_taps);
+        hipLaunchKernelGGL(k_det_blur, grid, block, 0, st, (const double *)d_tmp, d_g, rows, cols, 1, (const double *)d_taps);
+        hipLaunchKernelGGL(k_det_chess, grid, block, 0, st, (const double *)d_g, d_R, rows, cols, rmax);
+        hipLaunchKernelGGL(k_det_peaks, grid, block, 0, st, (const double *)d_R, rows, cols, (const unsigned long long *)rmax,
+                           (Peak *)d_list, count, MAX_PEAKS);
+        hipLaunchKernelGGL(k_det_export, dim3(1), dim3(256), 0, st, (const Peak *)d_list, (const int *)count, MAX_PEAKS, h_count,
+                           h_peaks, h_flag, d_seq);
+        return hipGetLastError();
+    };
+    // the upload and the six image-wide launches of an image: one graph per image shape (no argument changes from image to image)
+    static const bool no_graph = getenv("CCAL_DETECT_NO_GRAPH") != nullptr;
+    const bool same = g_begin != nullptr && g_rows == rows && g_cols == cols && g_sr == sr && g_sc == sc;
+    if (!no_graph && !same) {
+        // built node by node (not captured: a capture is invalidated by what other host threads do meanwhile -- the reference
+        // runs its detection under Threads.@threads, test/runtests.jl:45-51)
+        if (g_begin) { (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(g_begin)); g_begin = nullptr; }
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        bool built = hipGraphCreate(&graph, 0) == hipSuccess;
+        hipGraphNode_t prev = nullptr;
+        if (built) {
+            hipGraphNode_t node = nullptr;
+            built = hipGraphAddMemcpyNode1D(&node, graph, nullptr, 0, d_raw, h_pin + PIN_IMG, (size_t)span, hipMemcpyHostToDevice) == hipSuccess;
+            prev = node;
+        }
+        const dim3 grid((cols + 255) / 256, rows), block(256);
+        unsigned long long *rmax = reinterpret_cast<unsigned long long *>(d_misc);
+        int *count = reinterpret_cast<int *>(d_misc) + 4;
+        auto add = [&](void *fn, dim3 g, dim3 b, void **args) {
+            if (!built) return;
+            hipKernelNodeParams kp;
+            memset(&kp, 0, sizeof kp);
+            kp.func = fn; kp.gridDim = g; kp.blockDim = b; kp.sharedMemBytes = 0; kp.kernelParams = args; kp.extra = nullptr;
+            hipGraphNode_t node = nullptr;
+            built = hipGraphAddKernelNode(&node, graph, &prev, 1, &kp) == hipSuccess;
+            prev = node;
+        };
+        {
+            const uint8_t *a_raw = d_raw; long long a_sr = sr, a_sc = sc; double *a_img = d_img; int a_rows = rows, a_cols = cols;
+            void *args[] = {&a_raw, &a_sr, &a_sc, &a_img, &a_rows, &a_cols, &rmax};
+            add(reinterpret_cast<void *>(k_det_load), grid, block, args);
+        }
+        {
+            const double *a_src = d_img, *a_taps = d_taps; double *a_dst = d_tmp; int a_rows = rows, a_cols = cols, a_dir = 0;
+            void *args[] = {&a_src, &a_dst, &a_rows, &a_cols, &a_dir, &a_taps};
+            add(reinterpret_cast<void *>(k_det_blur), grid, block, args);
+        }
+        {
+            const double *a_src = d_tmp, *a_taps = d_taps; double *a_dst = d_g; int a_rows = rows, a_cols = cols, a_dir = 1;
+            void *args[] = {&a_src, &a_dst, &a_rows, &a_cols, &a_dir, &a_taps};
+            add(reinterpret_cast<void *>(k_det_blur), grid, block, args);
+        }
+        {
+            const double *a_g = d_g; double *a_R = d_R; int a_rows = rows, a_cols = cols;
+            void *args[] = {&a_g, &a_R, &a_rows, &a_cols, &rmax};
+            add(reinterpret_cast<void *>(k_det_chess), grid, block, args);
+        }
+        {
+            const double *a_R = d_R; int a_rows = rows, a_cols = cols, a_cap = MAX_PEAKS; const unsigned long long *a_rmax = rmax; Peak *a_list = (Peak *)d_list;
+            void *args[] = {&a_R, &a_rows, &a_cols, &a_rmax, &a_list, &count, &a_cap};
+            add(reinterpret_cast<void *>(k_det_peaks), grid, block, args);
+        }
+        {
+            const Peak *a_list = (const Peak *)d_list; const int *a_count = count; int a_cap = MAX_PEAKS;
+            void *args[] = {&a_list, &a_count, &a_cap, &h_count, &h_peaks, &h_flag, &d_seq};
+            add(reinterpret_cast<void *>(k_det_export), dim3(1), dim3(256), args);
+        }
+        if (built && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+            g_begin = exec; g_rows = rows; g_cols = cols; g_sr = sr; g_sc = sc;
+        }
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+    }
+    ++pin_seq;
+    if (!no_graph && g_begin != nullptr) {
+        const hipError_t e = hipGraphLaunch(static_cast<hipGraphExec_t>(g_begin), stream);
+        if (e != hipSuccess) { seq_resync = true; --pin_seq; err = std::string("hipGraphLaunch: ") + hipGetErrorString(e); return -5; }
+    } else {
+        const hipError_t e = enqueue(stream);
+        if (e != hipSuccess) { seq_resync = true; --pin_seq; err = std::string("detector launches: ") + hipGetErrorString(e); return -5; }
+    }
     return 0;
 }
 
@@ -554,8 +648,9 @@ int Detector::mid(hipStream_t stream, int n1, int n2, double *stage_out, std::st
     // raster order; the sub-pixel kernel reads the list from, and writes the refined corners to, the pinned block
     memcpy(h_peaks, peaks.data(), sizeof(Peak) * n);
     hipLaunchKernelGGL(k_det_subpix, dim3(n), dim3(64), 0, stream, (const double *)d_img, cur_rows, cur_cols, (const Peak *)h_peaks, n, h_sub,
-                       reinterpret_cast<unsigned int *>(d_misc) + 8, h_flag, ++pin_seq);
-    DCHK(hipGetLastError());
+                       reinterpret_cast<unsigned int *>(d_misc) + 8, h_flag, reinterpret_cast<unsigned long long *>(d_misc) + 8);
+    if (hipGetLastError() != hipSuccess) { seq_resync = true; err = "k_det_subpix launch failed"; return -5; }
+    ++pin_seq;
     cur_refining = true;
     return 0;
 }

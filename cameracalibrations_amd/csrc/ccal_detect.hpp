@@ -34,6 +34,12 @@ class Detector {
     int cur_rows = 0, cur_cols = 0, cur_n = 0;
     long long cur_sr = 0, cur_sc = 0;
     bool cur_refining = false;
+    // the upload + six image-wide launches of begin() as one replayable graph per image shape; the completion words count a
+    // device-side sequence number that pin_seq mirrors (seq_resync: set the device's from the host's before the next image)
+    void *g_begin = nullptr;
+    int g_rows = 0, g_cols = 0;
+    long long g_sr = 0, g_sc = 0;
+    bool seq_resync = true;
     void *cur_peaks = nullptr;     // std::vector<Peak> of the image in flight (opaque here: Peak lives in the .hip)
     void release();
     uint8_t *d_raw = nullptr;
