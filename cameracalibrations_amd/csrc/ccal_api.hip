@@ -226,16 +226,19 @@ int ccal_create(int device, ccal_ctx **out) {
     HIPCHK(hipMalloc(&c->d_st_scratch, sizeof(LmState) * 2));
     HIPCHK(hipMalloc(&c->d_red, sizeof(double) * NRED));
     HIPCHK(hipMalloc(&c->d_acc, ACC_BYTES));
-    HIPCHK(hipMemset(c->d_acc, 0, ACC_BYTES));                 // a new context starts in the steady state every solve leaves behind (accumulators
+    // (clears on the context's own stream, not on the legacy default stream: an operation there fails outright while another host
+    //  thread has a stream in capture mode)
+    HIPCHK(hipMemsetAsync(c->d_acc, 0, ACC_BYTES, c->own_stream));                 // a new context starts in the steady state every solve leaves behind (accumulators
     c->acc_dirty = false;                                      // all zero): its first fit needs no clears and can share merged launches
     HIPCHK(hipMalloc(&c->d_acc_scratch, ACC_BYTES));
-    HIPCHK(hipMemset(c->d_acc_scratch, 0, ACC_BYTES));
+    HIPCHK(hipMemsetAsync(c->d_acc_scratch, 0, ACC_BYTES, c->own_stream));
     HIPCHK(hipMalloc(&c->d_foc_red, sizeof(double) * NFOC));
     HIPCHK(hipMalloc(&c->d_foc_acc, sizeof(long long) * 2 * LM_FOC_ACC_WORDS));
-    HIPCHK(hipMemset(c->d_foc_acc, 0, sizeof(long long) * 2 * LM_FOC_ACC_WORDS));
+    HIPCHK(hipMemsetAsync(c->d_foc_acc, 0, sizeof(long long) * 2 * LM_FOC_ACC_WORDS, c->own_stream));
     c->foc_dirty = false;
     HIPCHK(hipMalloc(&c->d_fail, sizeof(int) * 4));
-    HIPCHK(hipMemset(c->d_fail, 0, sizeof(int) * 4));
+    HIPCHK(hipMemsetAsync(c->d_fail, 0, sizeof(int) * 4, c->own_stream));
+    HIPCHK(hipStreamSynchronize(c->own_stream));
     HIPCHK(hipMalloc(&c->d_intr0, sizeof(double) * 9));
     HIPCHK(hipMalloc(&c->d_intr_scratch, sizeof(double) * 9));
     HIPCHK(hipMalloc(&c->d_trace, sizeof(TraceRec) * c->max_trace));
@@ -989,9 +992,17 @@ static int lm_begin(ccal_ctx *c) {
         key.N = c->N; key.P = c->P; key.wpi = c->wpi; key.batch = c->lm_batch; key.init = make_init(c);
         if (c->graph_dirty || !c->g_first || memcmp(&key, &c->graph_key, sizeof key) != 0) {
             const int rc = capture_graph(c, &c->g_first);
-            if (rc) return rc;
-            c->graph_key = key;
-            c->graph_dirty = false;
+            if (rc) {
+                // a stream capture can be invalidated by what other host threads do meanwhile (allocations, synchronous copies):
+                // this solve is launched kernel by kernel -- same kernels, same bits -- and the next one captures again
+                (void)hipGetLastError();
+                if (c->g_first) { (void)hipGraphExecDestroy(c->g_first); c->g_first = nullptr; }
+                c->run_graphed = false;
+                c->graph_dirty = true;
+            } else {
+                c->graph_key = key;
+                c->graph_dirty = false;
+            }
         }
     }
     const double t_enq0 = now_s();

@@ -511,7 +511,8 @@ int Detector::begin(hipStream_t stream, const uint8_t *gray, int rows, int cols,
         DCHK(hipMalloc(&d_R, px * 8));
         DCHK(hipMalloc(&d_list, sizeof(Peak) * MAX_PEAKS)); DCHK(hipMalloc(&d_out, sizeof(double) * 2 * MAX_PEAKS));
         DCHK(hipMalloc(&d_misc, 128)); DCHK(hipMalloc(&d_taps, sizeof(double) * (2 * BLUR_R + 1)));
-        DCHK(hipMemset(d_misc, 0, 128));
+        DCHK(hipMemsetAsync(d_misc, 0, 128, stream));       // (on the caller's stream: nothing on the legacy default stream, which fails
+                                                            //  while another host thread captures a stream)
         seq_resync = true;              // (the device-side sequence counter of the new buffer starts at the host's)
         DCHK(hipHostMalloc(reinterpret_cast<void **>(&h_pin), PIN_IMG + px, hipHostMallocMapped));
         memset(h_pin, 0, PIN_PEAKS);
@@ -519,7 +520,8 @@ int Detector::begin(hipStream_t stream, const uint8_t *gray, int rows, int cols,
         double taps[2 * BLUR_R + 1], s = 0.0;
         for (int i = -BLUR_R; i <= BLUR_R; i++) s += taps[i + BLUR_R] = std::exp(-0.5 * i * i);
         for (double &t : taps) t /= s;
-        DCHK(hipMemcpy(d_taps, taps, sizeof taps, hipMemcpyHostToDevice));
+        DCHK(hipMemcpyAsync(d_taps, taps, sizeof taps, hipMemcpyHostToDevice, stream));
+        DCHK(hipStreamSynchronize(stream));
         cap_px = px;
     }
     unsigned long long *h_flag = reinterpret_cast<unsigned long long *>(h_pin);
@@ -532,7 +534,8 @@ int Detector::begin(hipStream_t stream, const uint8_t *gray, int rows, int cols,
     unsigned long long *d_seq = reinterpret_cast<unsigned long long *>(d_misc) + 8;
     if (seq_resync) {
         DCHK(hipStreamSynchronize(stream));
-        DCHK(hipMemcpy(d_seq, &pin_seq, sizeof pin_seq, hipMemcpyHostToDevice));
+        DCHK(hipMemcpyAsync(d_seq, &pin_seq, sizeof pin_seq, hipMemcpyHostToDevice, stream));
+        DCHK(hipStreamSynchronize(stream));
         seq_resync = false;
     }
     auto enqueue = [&](hipStream_t st) -> hipError_t {
@@ -636,8 +639,9 @@ int Detector::mid(hipStream_t stream, int n1, int n2, double *stage_out, std::st
     if (rc) return rc;
     int n = *h_count;
     if (stage_out) {          // diagnostics: blurred image and response for stage-wise parity tests
-        DCHK(hipMemcpy(stage_out, d_g, px * 8, hipMemcpyDeviceToHost));
-        DCHK(hipMemcpy(stage_out + px, d_R, px * 8, hipMemcpyDeviceToHost));
+        DCHK(hipMemcpyAsync(stage_out, d_g, px * 8, hipMemcpyDeviceToHost, stream));
+        DCHK(hipMemcpyAsync(stage_out + px, d_R, px * 8, hipMemcpyDeviceToHost, stream));
+        DCHK(hipStreamSynchronize(stream));
     }
     if (n > MAX_PEAKS) n = MAX_PEAKS;
     cur_n = n;

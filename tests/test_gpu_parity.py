@@ -1406,3 +1406,25 @@ def test_fit_many_equals_one_fit_at_a_time(golden_dir):
         b = fit_model(ex["image_size_wh"], obj, sub, ex["n_corners"], True, 1)
         assert (a.frow, a.fcol, a.crow, a.ccol, a.k, a.rms, a.iters) == (b.frow, b.fcol, b.crow, b.ccol, b.k, b.rms, b.iters)
         assert np.array_equal(np.array(a.Rs), np.array(b.Rs)) and np.array_equal(np.array(a.ts), np.array(b.ts))
+
+
+def test_fits_from_several_host_threads():
+    """The reference runs its per-file work under Threads.@threads (test/runtests.jl:45-51); a caller may well fit from several
+    host threads too.  Each thread has its own cached context (ccal_calibrate) and its own Solver; problems of changing sizes force
+    graph re-builds while other threads allocate, copy and launch.  Every result must equal the single-threaded one."""
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = [("REF", 6), ("C1", 25), ("C2", 40), ("REF", 3), ("C5", 5), ("C2", 130), ("C1", 9), ("REF", 12)]
+    wls = [syn.named_workload(n, n_images=k, seed_offset=7 * i) for i, (n, k) in enumerate(jobs)]
+
+    def one(i):
+        wl = wls[i % len(wls)]
+        m = fit_model(wl.image_size, wl.obj, list(wl.img), wl.n_corners, bool(wl.flags & syn.FIX_K1) is False, wl.aspect)
+        with _solver(wl, REF) as s:
+            st = s.fit()
+            r = s.result()
+        return (m.frow, m.fcol, m.crow, m.ccol, m.k, m.rms, m.iters), (st, r["iters"], r["rms"], r["intr"].tobytes())
+    serial = [one(i) for i in range(len(wls))]
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        threaded = list(pool.map(one, range(4 * len(wls))))
+    for i, res in enumerate(threaded):
+        assert res == serial[i % len(wls)], i
