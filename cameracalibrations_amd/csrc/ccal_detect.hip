@@ -557,7 +557,15 @@ int Detector::begin(hipStream_t stream, const uint8_t *gray, int rows, int cols,
     // the upload and the six image-wide launches of an image: one graph per image shape (no argument changes from image to image)
     static const bool no_graph = getenv("CCAL_DETECT_NO_GRAPH") != nullptr;
     const bool same = g_begin != nullptr && g_rows == rows && g_cols == cols && g_sr == sr && g_sc == sc;
-    if (!no_graph && !same) {
+    // (a graph is built for the SECOND image in a row of a shape: a caller that alternates shapes launches directly and never pays for
+    //  graphs it would use once)
+    const bool repeat = last_rows == rows && last_cols == cols && last_sr == sr && last_sc == sc;
+    last_rows = rows; last_cols = cols; last_sr = sr; last_sc = sc;
+    if (!no_graph && !same && g_begin != nullptr && !repeat) {
+        (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(g_begin));      // (another shape: the old graph's buffers may be re-sized)
+        g_begin = nullptr;
+    }
+    if (!no_graph && !same && repeat) {
         // built node by node (not captured: a capture is invalidated by what other host threads do meanwhile -- the reference
         // runs its detection under Threads.@threads, test/runtests.jl:45-51)
         if (g_begin) { (void)hipGraphExecDestroy(static_cast<hipGraphExec_t>(g_begin)); g_begin = nullptr; }

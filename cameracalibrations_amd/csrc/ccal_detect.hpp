@@ -40,6 +40,8 @@ class Detector {
     int g_rows = 0, g_cols = 0;
     long long g_sr = 0, g_sc = 0;
     bool seq_resync = true;
+    int last_rows = 0, last_cols = 0;
+    long long last_sr = 0, last_sc = 0;
     void *cur_peaks = nullptr;     // std::vector<Peak> of the image in flight (opaque here: Peak lives in the .hip)
     void release();
     uint8_t *d_raw = nullptr;
