@@ -131,6 +131,9 @@ struct ccal_ctx {
         LmInit init;
     } graph_key{};
     bool run_merged = false;      // this solve's launches were merged with other contexts' (ccal_stats.sweep_form bit 16)
+    hipEvent_t ev_join = nullptr; // merged launches run on another context's stream: whatever is still pending on this one is ordered in front of them
+    bool join_needed = false;     // ... which can only be the case after a deferred wait (staged inputs copied by a launch nobody waited for) or a
+                                  // solve of its own (the host is released by the progress word, ahead of the terminating launch's last stores)
     bool recording = false;       // ccal_fit_many is recording this context's launches for a merged launch (kernel by kernel, no graph)
     bool use_merge = true;        // (CCAL_NO_MERGE=1: ccal_fit_many enqueues every context's pipeline on its own stream)
     bool defer_sync = false;      // one-shot path: stage syncs and checks are batched at the end
@@ -274,6 +277,7 @@ void ccal_destroy(ccal_ctx *c) {
     (void)hipHostFree(c->h_st); (void)hipHostFree(c->h_flags); (void)hipHostFree(c->h_pin); (void)hipFree(c->d_scratch);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (auto &e : c->ev) (void)hipEventDestroy(e);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c->comm;
     delete c->p2p;
     delete c->detector;
@@ -501,7 +505,7 @@ int ccal_set_problem(ccal_ctx *c, const float *obj, int32_t P, int32_t N, int32_
     }
     // (no clearing of blk / ext0: a solve's first launch reads the six pose words of ext0 and nothing of blk, and every sweep
     //  writes its images' blocks whole -- two memset launches per call were a tenth of a reference-sized fit)
-    if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));   // `obj` may be released by the caller after return
+    if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream)); else c->join_needed = true;   // `obj` may be released by the caller after return
     c->P = P; c->N = N; c->width = width; c->height = height; c->aspect = aspect; c->flags = flags;
     c->max_iter = max_iter; c->eps = eps;
     resolve_wpi(c);
@@ -554,7 +558,7 @@ int ccal_set_image_points(ccal_ctx *c, const float *img_host) {
         }
         HIPCHK(hipMemcpyAsync(c->d_img_own, img_host, need, hipMemcpyHostToDevice, c->stream));
     }
-    if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));
+    if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream)); else c->join_needed = true;
     c->d_img = c->d_img_own;
     c->have_img = true;
     c->have_H = false;
@@ -594,7 +598,7 @@ int ccal_set_intrinsics(ccal_ctx *c, const double intr[CCAL_NINTR]) {
     for (int a = 4; a < CCAL_NINTR; a++) c->intr_distorted = c->intr_distorted || intr[a] != 0.0;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d_intr0, c->intr0, sizeof c->intr0, hipMemcpyHostToDevice, c->stream));
-    if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream));
+    if (!c->defer_sync) HIPCHK(hipStreamSynchronize(c->stream)); else c->join_needed = true;
     c->have_intr = true;
     c->have_result = false;
     return CCAL_OK;
@@ -973,6 +977,7 @@ static int lm_begin(ccal_ctx *c) {
     // A few images on one GPU: every trial in ONE launch of one workgroup (k_lm_trial<.., SOLO>): the trial-to-trial hand-off is a
     // workgroup barrier instead of a kernel boundary + accumulator round trip; same bits as the launch-per-trial form
     c->run_solo = c->use_solo && !sharded(c) && !c->time_sweeps && c->N <= lm_solo_max_images();
+    if (!c->recording) c->join_needed = true;      // (launches of its own on this stream: see fit_begin_merged)
     if (c->run_solo) {
         const double t_enq0 = now_s();
         TrialLaunch t = base_launch(c);
@@ -1028,6 +1033,7 @@ static bool lm_unfinished(const ccal_ctx *c) { return !c->h_st->done && c->run_t
 
 static int lm_more(ccal_ctx *c) {
     HIPCHK(hipSetDevice(c->device));
+    c->join_needed = true;
     int rc;
     const int more = c->lm_batch < 4 ? 4 : c->lm_batch;
     for (int k = 0; k < more; k++)
@@ -1207,7 +1213,7 @@ struct MergeArena {
     size_t cap = 0;
     hipEvent_t ev = nullptr;
 };
-static thread_local MergeArena t_arena[2];   // tables of the merged initialisation launches | of the merged solves
+static thread_local MergeArena t_arena[16][2];   // per device: tables of the merged initialisation launches | of the merged solves
 
 // ... and one set of contexts per (host thread, device list) for ccal_calibrate_multi
 struct MultiSet {
@@ -1232,14 +1238,15 @@ void ccal_thread_cleanup(void) {
     for (auto &c : t_cached) { if (c) ccal_destroy(c); c = nullptr; }
     for (auto &pool : t_pool) { for (auto c : pool) ccal_destroy(c); pool.clear(); }
     if (t_segs) { (void)hipHostFree(t_segs); t_segs = nullptr; t_segs_cap = 0; }
-    for (auto &A : t_arena)
-        if (A.d) {
-            (void)hipSetDevice(A.device);
-            (void)hipDeviceSynchronize();
-            (void)hipFree(A.d); (void)hipHostFree(A.h);
-            if (A.ev) (void)hipEventDestroy(A.ev);
-            A = MergeArena();
-        }
+    for (auto &dev_arenas : t_arena)
+        for (auto &A : dev_arenas)
+            if (A.d) {
+                (void)hipSetDevice(A.device);
+                (void)hipDeviceSynchronize();
+                (void)hipFree(A.d); (void)hipHostFree(A.h);
+                if (A.ev) (void)hipEventDestroy(A.ev);
+                A = MergeArena();
+            }
     for (auto &m : t_multi) multi_destroy(m);
     t_multi.clear();
 }
@@ -1456,6 +1463,7 @@ static bool fit_begin_merged(ccal_ctx *const *ctxs, const std::vector<int> &idx,
     std::vector<MergeRecorder> rec((size_t)m);
     static const bool dbg = getenv("CCAL_DEBUG_TIMING") != nullptr;
     ccal_ctx *c0 = ctxs[idx[0]];
+    MergeArena *arena = t_arena[c0->device];      // (a thread's merged calls on another device keep their own tables: no release / re-allocation per call)
     struct Launch { int kernel, key, grid, k, first, final_only; size_t pos, dyn, off_map, off_first, off_nblk; std::vector<int> who; };
 
     // records [lo, hi) of every context -> tables (one per kernel kind in `kinds`, entry = context) + launches, through arena A
@@ -1552,9 +1560,26 @@ static bool fit_begin_merged(ccal_ctx *const *ctxs, const std::vector<int> &idx,
         for (int e = 0; e < m; e++) merge_poison(ctxs[idx[e]]);     // nothing was launched: the ordinary path starts every one of them afresh
         return false;
     }
+    // The merged launches run on c0's stream only.  Whatever a participant may still have pending on a stream of its OWN -- the copy
+    // launch of inputs staged by ccal_calibrate_many when fewer than four calibrations were small, a deferred upload, the last stores of
+    // the terminating launch of an earlier ccal_fit -- is ordered in front of them: an event on that stream, waited for by c0's.  The
+    // library knows when that can be the case for a stream it owns (join_needed; never in the steady state of ccal_fit_many, whose
+    // contexts were last used by merged launches); a caller's stream (ccal_set_stream) is always joined.
+    for (int e = 1; e < m && ok; e++) {
+        ccal_ctx *c = ctxs[idx[e]];
+        if (c->stream == c0->stream || (!c->join_needed && c->stream == c->own_stream)) continue;
+        if (c->ev_join == nullptr && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { ok = false; break; }
+        if (hipEventRecord(c->ev_join, c->stream) != hipSuccess || hipStreamWaitEvent(c0->stream, c->ev_join, 0) != hipSuccess) ok = false;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        for (int e = 0; e < m; e++) merge_poison(ctxs[idx[e]]);
+        return false;
+    }
+    for (int e = 0; e < m; e++) ctxs[idx[e]]->join_needed = false;
     size_t n_launches = 0;
     static const bool one_step = getenv("CCAL_MERGE_ONE_STEP") != nullptr;     // (experiments: everything recorded before anything is launched)
-    hipError_t he = one_step ? hipSuccess : merge_and_launch(t_arena[0], 0, 2, {MERGE_HOMOGRAPHY, MERGE_EXTRINSICS}, n_launches);
+    hipError_t he = one_step ? hipSuccess : merge_and_launch(arena[0], 0, 2, {MERGE_HOMOGRAPHY, MERGE_EXTRINSICS}, n_launches);
     // (from here on launches are in flight: a failure is a HIP error and fails the contexts, it cannot fall back)
     if (he != hipSuccess) { fail_all(he); return true; }
     const double t1 = now_s();
@@ -1578,17 +1603,18 @@ static bool fit_begin_merged(ccal_ctx *const *ctxs, const std::vector<int> &idx,
         }
         len = std::max(len, rec[e].recs.size());
     }
-    if (one_step && (he = merge_and_launch(t_arena[0], 0, 2, {MERGE_HOMOGRAPHY, MERGE_EXTRINSICS}, n_launches)) != hipSuccess) { fail_all(he); return true; }
-    if (len > 2) he = merge_and_launch(t_arena[1], 2, len, {MERGE_LM}, n_launches);
+    if (one_step && (he = merge_and_launch(arena[0], 0, 2, {MERGE_HOMOGRAPHY, MERGE_EXTRINSICS}, n_launches)) != hipSuccess) { fail_all(he); return true; }
+    if (len > 2) he = merge_and_launch(arena[1], 2, len, {MERGE_LM}, n_launches);
     for (int e = 1; e < m && he == hipSuccess; e++)
-        if (ctxs[idx[e]]->stream != c0->stream) he = hipStreamWaitEvent(ctxs[idx[e]]->stream, t_arena[1].ev ? t_arena[1].ev : t_arena[0].ev, 0);
+        if (ctxs[idx[e]]->stream != c0->stream) he = hipStreamWaitEvent(ctxs[idx[e]]->stream, arena[1].ev ? arena[1].ev : arena[0].ev, 0);
     if (dbg) fprintf(stderr, "[ccal] fit_many merged: %d contexts, %zu launches; initialisation recorded + launched in %.1f us, solves in %.1f us\n", m,
                      n_launches, 1e6 * (t1 - t0), 1e6 * (now_s() - t1));
     if (he != hipSuccess) fail_all(he);
     return true;
 }
 
-int ccal_fit_many(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out) {
+// (errs != NULL: every failing context's own message, for ccal_calibrate_many)
+static int fit_many_impl(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out, std::vector<std::string> *errs) {
     if (n < 0 || (n > 0 && !ctxs)) return fail(CCAL_E_ARG, "ccal_fit_many: bad arguments");
     for (int a = 0; a < n; a++)
         for (int b = 0; b < a; b++)
@@ -1624,13 +1650,16 @@ int ccal_fit_many(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out) {
     for (int a = 0; a < n; a++) {
         const int rc = fit_end(ctxs[a], ph[a]);
         if (status_out) status_out[a] = rc;
+        if (rc < 0 && errs) (*errs)[(size_t)a] = g_err;
         if (rc < 0 && worst >= 0) { worst = rc; worst_err = "context " + std::to_string(a) + ": " + g_err; }
-        else if (rc > worst && worst >= 0) worst = rc;
+        else if (rc > 0 && worst >= 0) worst |= rc;    // the positive statuses are warning bits: the call returns their union
     }
     if (dbg && dbg_calls % 20 == 0) fprintf(stderr, "[ccal] fit_many: waits + checks %.1f us for %d contexts\n", 1e6 * (now_s() - t_end0), n);
     if (worst < 0) g_err = worst_err;
     return worst;
 }
+
+int ccal_fit_many(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out) { return fit_many_impl(ctxs, n, status_out, nullptr); }
 
 // fit_model for n calibrations of one caller (shared template, image size, flags, criteria), host arrays in and out like
 // ccal_calibrate: a pool of contexts of this thread, small inputs staged through each context's pinned block on ONE stream (a copy
@@ -1700,13 +1729,13 @@ int ccal_calibrate_many(const float *obj, int32_t P, int32_t n, const float *con
         return fail(CCAL_E_DEVICE, "ccal_calibrate_many: copy launch failed");
     }
     std::vector<int32_t> st_live(live.size(), 0);
-    (void)ccal_fit_many(live.data(), (int32_t)live.size(), st_live.data());
-    const std::string many_err = g_err;
+    std::vector<std::string> errs_live(live.size());
+    (void)fit_many_impl(live.data(), (int32_t)live.size(), st_live.data(), &errs_live);
     for (size_t q = 0; q < live.size(); q++) {
         ccal_ctx *c = live[q];
         const int i = live_i[q];
         int rc = st_live[q];
-        if (rc < 0) { st[i] = rc; errs[i] = many_err; continue; }
+        if (rc < 0) { st[i] = rc; errs[i] = errs_live[q]; continue; }
         double *o = out[i];
         const double *pose_rows = c->host_poses;      // written by the launch that found the solve done, ahead of its progress word
         if (pose_rows == nullptr) {
@@ -1733,7 +1762,7 @@ int ccal_calibrate_many(const float *obj, int32_t P, int32_t n, const float *con
         c->stream = c->own_stream;
         if (status_out) status_out[i] = st[i];
         if (st[i] < 0 && worst >= 0) { worst = st[i]; g_err = "calibration " + std::to_string(i) + ": " + errs[i]; }
-        else if (st[i] > worst && worst >= 0) worst = st[i];
+        else if (st[i] > 0 && worst >= 0) worst |= st[i];    // (union of the warning bits)
     }
     return worst;
 }

@@ -206,15 +206,16 @@ int  ccal_fit(ccal_ctx *ctx);
  * device whose fits are small (at most 128 workgroups per sweep: up to 128 images of a one-pass board) and in their steady state
  * (a fit before on the same context) do not even get launches of their own: their kernels are merged into one launch per
  * pipeline stage whose workgroups look their own fit up in a table (ccal_stats.sweep_form bit 16; CCAL_NO_MERGE=1 disables).  status_out[i] (may be
- * NULL) = what ccal_fit would have returned for context i; the return value is the first failure, else the largest
- * warning; ccal_last_error() then names that context. */
+ * NULL) = what ccal_fit would have returned for context i; the return value is the first failure (ccal_last_error() then names
+ * that context), else the UNION of the contexts' warning bits (CCAL_W_*). */
 int  ccal_fit_many(ccal_ctx *const *ctxs, int32_t n, int32_t *status_out);
 /* ccal_calibrate (= fit_model, src/detect_fit.jl:27-61) for n calibrations of one caller: template obj [P][3], image size, aspect,
  * flags and criteria shared; img[i] -> [N[i]][P][2] float32 corners of calibration i; results packed per calibration into
  * out[i]: K4 (4) | dist5 (5) | rms | iters | rvecs [N[i]][3] | tvecs [N[i]][3]   (11 + 6 N[i] doubles).
  * Host arrays in and out; contexts come from a pool of the calling thread (released by ccal_thread_cleanup / at thread exit);
  * the fits run through ccal_fit_many.  Same values as n calls of ccal_calibrate.  status_out[i] (may be NULL) per calibration;
- * returns the first failure, else the largest warning.  CCAL_USE_INTRINSIC_GUESS is not supported here (CCAL_E_ARG). */
+ * returns the first failure (ccal_last_error() = that calibration's own message), else the union of the warning bits.
+ * CCAL_USE_INTRINSIC_GUESS is not supported here (CCAL_E_ARG). */
 int  ccal_calibrate_many(const float *obj, int32_t P, int32_t n, const float *const *img, const int32_t *N, int32_t width,
                          int32_t height, double aspect, uint32_t flags, int32_t max_iter, double eps, int32_t device,
                          double *const *out, int32_t *status_out);

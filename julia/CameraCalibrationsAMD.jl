@@ -169,6 +169,8 @@ end
 # the images of one calibration (one size) in one call: three in flight on the device (include/ccal.h ccal_detect_corners_many)
 function detect_corners_many(c::Context, grays::Vector{Matrix{UInt8}}, n_corners)
     isempty(grays) && return []
+    # the C side reads rows x cols bytes from every pointer: images of another size go one by one
+    all(size(g) == size(grays[1]) for g in grays) || return [detect_corners(c, g, n_corners) for g in grays]
     rows, cols = size(grays[1]); n1, n2 = n_corners
     outs = [zeros(Float64, 2, n1 * n2) for _ in grays]; found = zeros(Int32, length(grays))
     GC.@preserve grays outs begin

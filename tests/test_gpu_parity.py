@@ -1408,6 +1408,46 @@ def test_fit_many_equals_one_fit_at_a_time(golden_dir):
         assert np.array_equal(np.array(a.Rs), np.array(b.Rs)) and np.array_equal(np.array(a.ts), np.array(b.ts))
 
 
+def test_fit_models_orders_staged_inputs_of_mixed_sizes_before_the_merged_launches():
+    """Two small calibrations (inputs staged in their pinned blocks and copied by a launch on their OWN streams, never waited for:
+    fewer than four small ones share no copy launch) next to three of 80 images (too large for the pinned block, small enough to
+    merge): five merge-able contexts, so all of them run in merged launches on the first context's stream -- which must wait for
+    the other streams' pending copies.  The pool's contexts are re-used with other corners from call to call, so a launch that ran
+    ahead of a copy would fit the previous call's corners.  Every calibration equals its own fit_model bit for bit, and the call's
+    status is the union of the calibrations' warning bits."""
+    from cameracalibrations_amd import _ffi as F, fit_models
+    shapes = [6, 80, 5, 80, 80]
+    for rep in range(6):
+        wls = [syn.named_workload("REF", n_images=k, seed_offset=1000 + 17 * rep + i) for i, k in enumerate(shapes)]
+        if rep % 2:
+            wls = wls[::-1]
+        wl0 = wls[0]
+        many = fit_models(wl0.image_size, wl0.obj, [list(w.img) for w in wls], wl0.n_corners, True, wl0.aspect)
+        for w, a in zip(wls, many):
+            b = fit_model(w.image_size, w.obj, list(w.img), w.n_corners, True, w.aspect)
+            assert (a.frow, a.fcol, a.crow, a.ccol, a.k, a.rms, a.iters) == (b.frow, b.fcol, b.crow, b.ccol, b.k, b.rms, b.iters), rep
+            assert np.array_equal(np.array(a.Rs), np.array(b.Rs)) and np.array_equal(np.array(a.ts), np.array(b.ts)), rep
+    # warning bits of several contexts: the call returns their union (one fit stopped by max_iter, the others clean)
+    wls = [syn.named_workload("C2", n_images=12, seed_offset=300 + i) for i in range(5)]
+    crits = [(1, 1e-12)] + [REF] * 4
+    solvers = [_solver(w, c) for w, c in zip(wls, crits)]
+    try:
+        from cameracalibrations_amd import fit_many
+        sts = fit_many(solvers, check=False)
+        assert sts[0] == F.W_MAX_ITER and all(st == 0 for st in sts[1:])
+        import ctypes as C
+        ptrs = (C.c_void_p * len(solvers))(*[s._h for s in solvers])
+        st_arr = (C.c_int32 * len(solvers))()
+        rc = F.lib().ccal_fit_many(ptrs, len(solvers), st_arr)
+        union = 0
+        for v in st_arr:
+            union |= int(v)
+        assert rc == union == F.W_MAX_ITER
+    finally:
+        for s in solvers:
+            s.close()
+
+
 def test_fits_from_several_host_threads():
     """The reference runs its per-file work under Threads.@threads (test/runtests.jl:45-51); a caller may well fit from several
     host threads too.  Each thread has its own cached context (ccal_calibrate) and its own Solver; problems of changing sizes force
