@@ -381,8 +381,9 @@ def many_block(contexts=32, rounds=25):
             return cc.board_template(ex["n_corners"]), (ex_img + rng.normal(0, 0.05, ex_img.shape)).astype(np.float32), ex["image_size_wh"], 1.0, reference_flags(True)
         wl = syn.named_workload(name, seed_offset=i)
         return wl.obj, wl.img, wl.image_size, wl.aspect, wl.flags
-    out = {"contexts": contexts, "what": "us per fit, median over rounds: the contexts' ccal_fit one after the other | one ccal_fit_many over all of them; "
-                                         "different problems of one shape, corners resident, results bit-equal (tests)"}
+    out = {"contexts": contexts, "what": "us per fit, median over rounds, each kind of call in its steady state: the contexts' ccal_fit one after the other | "
+                                         "ccal_fit_many over all of them, call after call | the same right after the contexts' own fits (one stream join "
+                                         "per context); different problems of one shape, corners resident, results bit-equal (tests)"}
     for name in ("ref_example", "C1", "C3"):
         solvers = []
         for i in range(contexts):
@@ -391,18 +392,27 @@ def many_block(contexts=32, rounds=25):
             s.set_problem(obj, img.shape[0], size, aspect=aspect, flags=flags, max_iter=CRITERIA[0], eps=CRITERIA[1])
             s.set_image_points(img)
             solvers.append(s)
-        t_seq, t_many = [], []
+        # each way of calling in ITS steady state (calls of one kind in a row); and the many-call right after the contexts' own fits,
+        # where every context whose last launches ran on its own stream is joined to the merged launches' stream once (an event each)
+        t_seq, t_many, t_after = [], [], []
         for rep in range(rounds + 3):
             t0 = time.perf_counter()
             for s in solvers:
                 s.fit()
-            t1 = time.perf_counter()
+            t_seq.append((time.perf_counter() - t0) / contexts)
+        for rep in range(rounds + 3):
+            t0 = time.perf_counter()
             cc.fit_many(solvers)
-            t2 = time.perf_counter()
-            t_seq.append((t1 - t0) / contexts)
-            t_many.append((t2 - t1) / contexts)
+            t_many.append((time.perf_counter() - t0) / contexts)
+        for rep in range(8):
+            for s in solvers:
+                s.fit()
+            t0 = time.perf_counter()
+            cc.fit_many(solvers)
+            t_after.append((time.perf_counter() - t0) / contexts)
         a, b = float(np.median(t_seq[3:])), float(np.median(t_many[3:]))
         out[name.lower()] = {"us_per_fit_one_at_a_time": 1e6 * a, "us_per_fit_many": 1e6 * b, "speedup": a / b,
+                             "us_per_fit_many_right_after_own_fits": 1e6 * float(np.median(t_after[2:])),
                              "images": int(img.shape[0]), "corners_per_image": int(img.shape[1])}
         for s in solvers:
             s.close()

@@ -22,7 +22,6 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
-#include <cstdlib>
 #include <map>
 #include <vector>
 
@@ -44,15 +43,7 @@ constexpr double REL_THRESHOLD = 0.15;
 constexpr int SUBPIX_WIN = 11;
 constexpr int SUBPIX_ITERS = 30;
 constexpr double SUBPIX_EPS = 1e-3;
-// A refinement that leaves its response peak by more than max_shift is not believed and the peak stands.  OpenCV's rule is the half
-// window (11 px); under strong shear a neighbouring corner's edges inside the 23 x 23 window pull a corner 1.5 ... 11 px away and the
-// lattice cannot close (profiles/r05_detector_probe.txt), hence 2 px -- as long as another response peak is within the window's reach
-// (its weight at a neighbour d pixels off is exp(-d^2 / 121): 0.04 at 20 px, 2e-6 at 40).  A peak with no other peak within
-// SUBPIX_FAR px (large squares, high-resolution or heavily blurred images: the integer peak itself may sit a few pixels from the
-// saddle, and nothing but the corner's own edges is inside the window) keeps OpenCV's bound.  A graded bound (2 px up to d = 20,
-// +0.5 px per pixel) was measured first and lost a sheared board the fixed 2 px keeps: profiles/r06_detector_probe.txt.
-constexpr double SUBPIX_MIN_SHIFT = 2.0, SUBPIX_FAR = 40.0;
-inline double subpix_max_shift(double d_nn) { return d_nn >= SUBPIX_FAR ? (double)SUBPIX_WIN : SUBPIX_MIN_SHIFT; }
+constexpr double SUBPIX_MAX_SHIFT = 2.0;
 constexpr double MERGE_DIST = 2.0;
 __device__ const int RING_DR[16] = {0, 2, 3, 5, 5, 5, 3, 2, 0, -2, -3, -5, -5, -5, -3, -2};
 __device__ const int RING_DC[16] = {5, 5, 3, 2, 0, -2, -3, -5, -5, -5, -3, -2, 0, 2, 3, 5};
@@ -272,10 +263,13 @@ __global__ __launch_bounds__(64) void k_det_subpix(const double *__restrict__ im
         if (!(qr >= 0.0 && qr < rows && qc >= 0.0 && qc < cols)) break;
         if (err <= SUBPIX_EPS * SUBPIX_EPS) break;
     }
-    // a refinement that leaves its response peak by more than this peak's bound (subpix_max_shift of its nearest-neighbour distance,
-    // worked out by the host and handed over in the list entry's value field) is not believed and the peak stands
-    const double max_shift = list[i].v;
-    if (fabs(qr - pr) > max_shift || fabs(qc - pc) > max_shift) { qr = pr; qc = pc; }
+    // a refinement that leaves its response peak by more than SUBPIX_MAX_SHIFT is not believed and the peak stands (OpenCV's rule uses
+    // the half window, 11 px; under strong shear a neighbouring edge inside the 23 x 23 window pulls corners 3-11 px away, the
+    // lattice then cannot close: oracle/detect_oracle.py, profiles/r05_detector_probe.txt).  Bounds that grow with the distance to
+    // the nearest other peak -- graded, or OpenCV's 11 px for peaks with no neighbour within 40 px -- were measured in round 6 and are
+    // worse: the graded one loses a sheared board, and on heavily blurred 2-megapixel boards the wide bound admits refinements 12 px
+    // off (mean corner error 1.35 px against 0.39 with the fixed 2 px): profiles/r06_detector_probe.txt
+    if (fabs(qr - pr) > SUBPIX_MAX_SHIFT || fabs(qc - pc) > SUBPIX_MAX_SHIFT) { qr = pr; qc = pc; }
     if (lane == 0) {
         out[2 * i] = qr; out[2 * i + 1] = qc;
         // `out` is pinned host memory: the last workgroup to finish raises the completion word the host spins on
@@ -666,23 +660,8 @@ int Detector::mid(hipStream_t stream, int n1, int n2, double *stage_out, std::st
     std::vector<Peak> &peaks = *static_cast<std::vector<Peak> *>(cur_peaks);
     peaks.assign(h_peaks, h_peaks + n);
     std::sort(peaks.begin(), peaks.end(), [&](const Peak &x, const Peak &y) { return x.r != y.r ? x.r < y.r : x.c < y.c; });
-    // raster order; the sub-pixel kernel reads the list from, and writes the refined corners to, the pinned block.  The kernel's copy
-    // of an entry carries the peak's revert bound instead of its response (which stays in `peaks` for the merge): distance to the
-    // nearest other peak -- in raster order only rows closer than the best distance so far need a look
+    // raster order; the sub-pixel kernel reads the list from, and writes the refined corners to, the pinned block
     memcpy(h_peaks, peaks.data(), sizeof(Peak) * n);
-    static const double fixed_shift = getenv("CCAL_DET_MAX_SHIFT") ? atof(getenv("CCAL_DET_MAX_SHIFT")) : 0.0;   // (experiments: one bound for all)
-    for (int i = 0; i < n; i++) {
-        double best = 1e300;
-        for (int j = i + 1; j < n && (double)(peaks[j].r - peaks[i].r) * (peaks[j].r - peaks[i].r) < best; j++) {
-            const double dr = peaks[j].r - peaks[i].r, dc = peaks[j].c - peaks[i].c;
-            best = std::min(best, dr * dr + dc * dc);
-        }
-        for (int j = i - 1; j >= 0 && (double)(peaks[i].r - peaks[j].r) * (peaks[i].r - peaks[j].r) < best; j--) {
-            const double dr = peaks[j].r - peaks[i].r, dc = peaks[j].c - peaks[i].c;
-            best = std::min(best, dr * dr + dc * dc);
-        }
-        h_peaks[i].v = fixed_shift > 0.0 ? fixed_shift : subpix_max_shift(sqrt(best));
-    }
     hipLaunchKernelGGL(k_det_subpix, dim3(n), dim3(64), 0, stream, (const double *)d_img, cur_rows, cur_cols, (const Peak *)h_peaks, n, h_sub,
                        reinterpret_cast<unsigned int *>(d_misc) + 8, h_flag, reinterpret_cast<unsigned long long *>(d_misc) + 8);
     if (hipGetLastError() != hipSuccess) { seq_resync = true; err = "k_det_subpix launch failed"; return -5; }

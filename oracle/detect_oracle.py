@@ -26,8 +26,6 @@ Coordinates: the image is the Julia matrix img[row, col]; a corner is RowCol = (
 pixel-centre coordinates, which is what OpenCV returns as (x, y) for the transposed view it is
 handed (reference src/detect_fit.jl:7).
 """
-import os
-
 import numpy as np
 
 SIGMA = 1.0
@@ -40,11 +38,7 @@ REL_THRESHOLD = 0.15
 SUBPIX_WIN = 11
 SUBPIX_ITERS = 30
 SUBPIX_EPS = 1e-3
-# A refinement that leaves its response peak by more than the peak's bound is not believed: the peak stands.  OpenCV's bound is the half
-# window, 11 px; under strong shear a neighbouring corner's edges inside the 23 x 23 window pull a corner away (the window's weight at a
-# neighbour d pixels off is exp(-d^2 / 121): 0.04 at 20 px, 2e-6 at 40), hence 2 px while another response peak is within SUBPIX_FAR px;
-# a peak with none that close keeps OpenCV's bound.
-SUBPIX_MIN_SHIFT, SUBPIX_FAR = 2.0, 40.0
+SUBPIX_MAX_SHIFT = 2.0    # a refinement that leaves its response peak by more than this is not believed: the peak stands (OpenCV: the half window, 11)
 MERGE_DIST = 2.0
 
 
@@ -104,15 +98,6 @@ def peaks(R):
     return a[:, :2].astype(np.float64), a[:, 2]
 
 
-def subpix_max_shift(pts):
-    p = np.asarray(pts, dtype=np.float64)
-    if len(p) < 2:
-        return np.full(len(p), float(SUBPIX_WIN))
-    d2 = ((p[:, None, :] - p[None, :, :]) ** 2).sum(axis=2)
-    np.fill_diagonal(d2, np.inf)
-    return np.where(np.sqrt(d2.min(axis=1)) >= SUBPIX_FAR, float(SUBPIX_WIN), SUBPIX_MIN_SHIFT)
-
-
 def _bilinear(im, rr, cc):
     h, w = im.shape
     rr = np.clip(rr, 0, h - 1)
@@ -135,8 +120,6 @@ def corner_subpix(im, pts):
     mask = np.outer(m1, m1)
     off = np.arange(-win, win + 1, dtype=np.float64)
     out = np.array(pts, dtype=np.float64)
-    fixed = float(os.environ.get("CCAL_DET_MAX_SHIFT", "0") or 0)      # (experiments: one bound for all peaks)
-    max_shift = np.full(len(out), fixed) if fixed > 0 else subpix_max_shift(pts)
     for i, (pr, pc) in enumerate(pts):
         qr, qc = float(pr), float(pc)
         for _ in range(SUBPIX_ITERS):
@@ -160,7 +143,7 @@ def corner_subpix(im, pts):
                 break
             if err <= SUBPIX_EPS * SUBPIX_EPS:
                 break
-        if abs(qr - pr) > max_shift[i] or abs(qc - pc) > max_shift[i]:
+        if abs(qr - pr) > SUBPIX_MAX_SHIFT or abs(qc - pc) > SUBPIX_MAX_SHIFT:
             qr, qc = float(pr), float(pc)
         out[i] = (qr, qc)
     return out

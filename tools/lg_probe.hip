@@ -1,7 +1,7 @@
-// Feasibility probe of the sweep in lane-group form (cameracalibrations_amd/csrc/ccal_lg.hpp): rows + Gram sums of N images x P corners
+// Feasibility probe of the sweep in lane-group form (tools/lg_probe_math.hpp): rows + Gram sums of N images x P corners
 // with L lanes per image and the sums in registers (pass A: pose blocks, reduced over the group's lanes and rotated per image; pass B:
 // intrinsic block, one total per wave), checked against point_rows_K on the host and timed.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-sched-strategy=max-ilp -I cameracalibrations_amd/csrc -o /tmp/lg_probe tools/lg_probe.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-sched-strategy=max-ilp -I cameracalibrations_amd/csrc -I tools -o /tmp/lg_probe tools/lg_probe.hip
 //   /tmp/lg_probe [N] [P1] [P2]
 #include <hip/hip_runtime.h>
 
@@ -11,7 +11,7 @@
 #include <random>
 #include <vector>
 
-#include "ccal_lg.hpp"
+#include "lg_probe_math.hpp"
 #include "ccal_wave.hpp"
 
 using namespace ccal;
@@ -28,8 +28,26 @@ __device__ __forceinline__ double group_sum(double v) {
     return v;
 }
 
+// one walk of a lane over every L-th corner of its image: the next corner's observation is requested before the current one's
+// arithmetic (one wave per SIMD or two: nobody else hides the load), the template comes from LDS
+template <int L, class F>
+__device__ __forceinline__ void walk(const float2 *__restrict__ ip, const double *__restrict__ s_obj, int P, int sub, F &&f) {
+    int p = sub;
+    float2 uv_n = ip[p < P ? p : 0];
+    for (; p < P; p += L) {
+        const float2 uv = uv_n;
+        const int pn = p + L;
+        uv_n = ip[pn < P ? pn : p];
+        const double M[3] = {s_obj[3 * p], s_obj[3 * p + 1], s_obj[3 * p + 2]};
+        f(M, (double)uv.x, (double)uv.y);
+    }
+}
+
 #ifndef LG_MINW
 #define LG_MINW 2
+#endif
+#ifndef LG_SPLIT_A
+#define LG_SPLIT_A 1
 #endif
 
 // MODE 0: timing (pass A per batch of 64 / L images with the group reduce and the rotation, pass B over all batches, one row of
@@ -39,7 +57,14 @@ __global__ __launch_bounds__(256, LG_MINW) void k_lg(const float2 *__restrict__ 
                                                       const double *__restrict__ ext, const double *__restrict__ intr, double aspect,
                                                       int N, int P, double *__restrict__ gram_out, double *__restrict__ wave_out) {
     constexpr int G = 64 / L;
+    // per wave: K and the reduced B~ of the batch's images are parked in LDS while the next walk over the corners runs (kept in
+    // registers they would stay live across it: 126 vector registers on top of the walk's own sums)
+    __shared__ double s_park[4 * G * (LG_NB + 9)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *park = s_park + (wave * G + (lane / L)) * (LG_NB + 9);
+    __shared__ double s_obj[3 * 256];                // the template as doubles (P <= 256 in this probe)
+    for (int k = threadIdx.x; k < 3 * P; k += 256) s_obj[k] = (double)obj[k];
+    __syncthreads();
     const int sub = lane % L, grp = lane / L;
     double in[NINTR];
 #pragma unroll
@@ -55,8 +80,15 @@ __global__ __launch_bounds__(256, LG_MINW) void k_lg(const float2 *__restrict__ 
         double e6[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) e6[k] = ext[(size_t)ii * 8 + k];
-        double R[9], K[9];
-        rodrigues_RK(e6, R, K);
+        double R[9];
+        {
+            double K[9];
+            rodrigues_RK(e6, R, K);
+            if (sub == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) park[LG_NB + k] = K[k];
+            }
+        }
         const double tv[3] = {e6[3], e6[4], e6[5]};
         double At[LG_NA], Bt[LG_NB], ht[LG_NH];
 #pragma unroll
@@ -66,21 +98,52 @@ __global__ __launch_bounds__(256, LG_MINW) void k_lg(const float2 *__restrict__ 
 #pragma unroll
         for (int k = 0; k < LG_NH; k++) ht[k] = 0.0;
         const float2 *ip = img + (size_t)ii * P;
-        for (int p = sub; p < P; p += L) {
-            const float2 uv = ip[p];
-            const double M[3] = {(double)obj[3 * p], (double)obj[3 * p + 1], (double)obj[3 * p + 2]};
+#if LG_SPLIT_A
+        // 54 + 27 sums in two walks over the corners (the rows are formed twice)
+        walk<L>(ip, s_obj, P, sub, [&](const double (&M)[3], double uo, double vo) {
             LgPoint q;
-            lg_project(M, (double)uv.x, (double)uv.y, R, tv, in, q);
+            lg_project(M, uo, vo, R, tv, in, q);
+            double cu[6], cv[6];
+            lg_pose_columns(q, in, cu, cv);
+            lg_accum_A1(q, cu, cv, Bt);
+        });
+#pragma unroll
+        for (int k = 0; k < LG_NB; k++) {
+            const double v = group_sum<L>(Bt[k]);
+            if (sub == 0) park[k] = v;
+        }
+        walk<L>(ip, s_obj, P, sub, [&](const double (&M)[3], double uo, double vo) {
+            LgPoint q;
+            lg_project(M, uo, vo, R, tv, in, q);
+            double cu[6], cv[6];
+            lg_pose_columns(q, in, cu, cv);
+            lg_accum_A2(q, cu, cv, At, ht);
+        });
+        wave_lds_sync();
+#pragma unroll
+        for (int k = 0; k < LG_NB; k++) Bt[k] = park[k];
+#else
+        walk<L>(ip, s_obj, P, sub, [&](const double (&M)[3], double uo, double vo) {
+            LgPoint q;
+            lg_project(M, uo, vo, R, tv, in, q);
             double cu[6], cv[6];
             lg_pose_columns(q, in, cu, cv);
             lg_accum_A(q, cu, cv, At, Bt, ht);
-        }
+        });
+#pragma unroll
+        for (int k = 0; k < LG_NB; k++) Bt[k] = group_sum<L>(Bt[k]);
+#endif
 #pragma unroll
         for (int k = 0; k < LG_NA; k++) At[k] = group_sum<L>(At[k]);
 #pragma unroll
-        for (int k = 0; k < LG_NB; k++) Bt[k] = group_sum<L>(Bt[k]);
-#pragma unroll
         for (int k = 0; k < LG_NH; k++) ht[k] = group_sum<L>(ht[k]);
+        double K[9];
+#if !LG_SPLIT_A
+        wave_lds_sync();
+#endif
+#pragma unroll
+        for (int k = 0; k < 9; k++) K[k] = park[LG_NB + k];
+        wave_lds_sync();
         lg_apply_T(K, At, Bt, ht);
         if (aspect > 0.0) lg_fold_aspect_B(aspect, Bt);
         if (MODE == 1) {
@@ -128,13 +191,11 @@ __global__ __launch_bounds__(256, LG_MINW) void k_lg(const float2 *__restrict__ 
             ee = 0.0;
         }
         if (act) {
-            for (int p = sub; p < P; p += L) {
-                const float2 uv = ip[p];
-                const double M[3] = {(double)obj[3 * p], (double)obj[3 * p + 1], (double)obj[3 * p + 2]};
+            walk<L>(ip, s_obj, P, sub, [&](const double (&M)[3], double uo, double vo) {
                 LgPoint q;
-                lg_project(M, (double)uv.x, (double)uv.y, R, tv, in, q);
+                lg_project(M, uo, vo, R, tv, in, q);
                 lg_accum_B(q, Ct, gt, ee);
-            }
+            });
         }
         if (MODE == 1) {
 #pragma unroll
@@ -163,6 +224,60 @@ __global__ __launch_bounds__(256, LG_MINW) void k_lg(const float2 *__restrict__ 
         s = wave_sum(s + chk);
         if (lane == 0) wave_out[wid] = s;
     }
+}
+
+// What the vector unit sustains chip-wide on FP64: NCH independent v_fma_f64 chains per lane, `iters` rounds, every wave; shader clock
+// from s_memtime against the 100 MHz s_memrealtime over the same interval.
+template <int NCH>
+__global__ __launch_bounds__(1024) void k_fma_rate(double *out, unsigned long long *clk, int iters, double y) {
+    double a[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; k++) a[k] = 1.0 + 1e-3 * (threadIdx.x + k);
+    unsigned long long t0, r0, t1, r1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0), "=s"(r0)::"memory");
+    // (128 instructions between two branches: a taken branch costs a wave ~30 cycles, which a loop of 16 would report as issue time)
+    constexpr int UNR = 128 / NCH;
+    for (int i = 0; i < iters; i += UNR) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++)
+#pragma unroll
+            for (int k = 0; k < NCH; k++) a[k] = fma(a[k], y, 1e-9);
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < NCH; k++) s += a[k];
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1) : "v"(s) : "memory");
+    if (s == 12345.678) out[0] = s;
+    if (threadIdx.x == 0 && blockIdx.x < 1024) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+template <int NCH>
+static void fma_rate_t(int grid, int block, int iters);
+static void fma_rate(int grid, int iters) { fma_rate_t<16>(grid, 256, iters); }
+template <int NCH>
+static void fma_rate_t(int grid, int block, int iters) {
+    double *d_out; unsigned long long *d_clk;
+    CK(hipMalloc(&d_out, 8)); CK(hipMalloc(&d_clk, 16 * 1024));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_fma_rate<NCH>), dim3(grid), dim3(block), 0, 0, d_out, d_clk, iters, 0.999999);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_fma_rate<NCH>), dim3(grid), dim3(block), 0, 0, d_out, d_clk, iters, 0.999999);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h[2048];
+    CK(hipMemcpy(h, d_clk, sizeof h, hipMemcpyDeviceToHost));
+    double cyc = 0, real = 0;
+    const int nb = grid < 1024 ? grid : 1024;
+    for (int b = 0; b < nb; b++) { cyc += (double)h[2 * b]; real += (double)h[2 * b + 1]; }
+    const double flop = 2.0 * NCH * (double)iters * (double)block * grid;
+    printf("  v_fma_f64 x %2d independent chains, grid %4d x %3d threads, %d rounds: %.1f us, %.1f TFLOP/s; shader clock %.2f GHz (s_memtime / "
+           "s_memrealtime); a wave issues one every %.2f cycles\n", NCH, grid, block, iters, 1e3 * ms, flop / (1e-3 * ms) * 1e-12, cyc / real * 0.1,
+           (cyc / nb) / ((double)NCH * iters));
+    CK(hipFree(d_out)); CK(hipFree(d_clk));
 }
 
 struct Problem {
@@ -261,7 +376,20 @@ int main(int argc, char **argv) {
     CK(hipMemcpy(d_obj, pr.obj.data(), sizeof(float) * pr.obj.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(d_ext, pr.ext.data(), sizeof(double) * pr.ext.size(), hipMemcpyHostToDevice));
     CK(hipMemcpy(d_intr, pr.intr.data(), sizeof(double) * 9, hipMemcpyHostToDevice));
-    printf("lane-group rows + Gram sums, %d images x %d corners (K = 9), min waves per SIMD hint %d\n", N, pr.P, LG_MINW);
+    printf("FP64 vector rate of the chip (78.6 TFLOP/s is the 2.4 GHz figure):\n");
+    for (int grid : {256, 512, 768, 1024, 2048}) fma_rate(grid, 4096);
+    printf("who shares what: one wave alone on the chip | one wave per compute unit | two | four (one per SIMD) | 1 of 4 compute units with four\n");
+    fma_rate_t<16>(1, 64, 4096);
+    fma_rate_t<16>(256, 64, 4096);
+    fma_rate_t<16>(256, 128, 4096);
+    fma_rate_t<16>(256, 256, 4096);
+    fma_rate_t<16>(64, 256, 4096);
+    printf("one dependent chain per wave (what a latency-bound wave sees): alone | one wave per SIMD everywhere\n");
+    fma_rate_t<1>(1, 64, 65536);
+    fma_rate_t<1>(256, 256, 65536);
+    fma_rate_t<2>(256, 256, 32768);
+    fma_rate_t<4>(256, 256, 16384);
+    printf("lane-group rows + Gram sums, %d images x %d corners (K = 9), min waves per SIMD hint %d, pose blocks in %d walk(s)\n", N, pr.P, LG_MINW, LG_SPLIT_A ? 2 : 1);
     for (int grid : {256, 512, 1024}) {
         run<4>(pr, 0.0, d_img, d_obj, d_ext, d_intr, d_gram, d_wave, grid, 20);
         run<8>(pr, 0.0, d_img, d_obj, d_ext, d_intr, d_gram, d_wave, grid, 20);

@@ -1,4 +1,4 @@
-// ccal_lg.hpp -- the sweep's per-corner arithmetic in "lane-group" form (saturated regime: many images per SIMD).
+// lg_probe_math.hpp -- the sweep's per-corner arithmetic in "lane-group" form (probe only: tools/lg_probe.hip, profiles/r06_lane_group_probe.txt).
 //
 // k_lm_trial's default form gives an image a whole wavefront: one corner per lane, the two 16-wide rows of [Je | Ji | e] go through
 // an LDS tile into v_mfma_f64_16x16x4_f64, and everything that is the same for all corners of the image (pose update, rotation,
@@ -88,18 +88,37 @@ CCAL_HD void lg_pose_columns(const LgPoint &q, const double in[NINTR], double cu
     cv[0] = q.Yr * w12 - q.Zr * w11; cv[1] = q.Zr * w10 - q.Xr * w12; cv[2] = q.Xr * w11 - q.Yr * w10;
 }
 
-// pass A, one corner: A~ += c~ c~^T (packed lower), B~ += c~ ji^T, h~ += c~ e   (138 multiply-adds)
+// pass A, one corner: A~ += c~ c~^T (packed lower), B~ += c~ ji^T, h~ += c~ e   (138 multiply-adds; 81 sums)
 CCAL_HD void lg_accum_A(const LgPoint &q, const double cu[6], const double cv[6], double At[LG_NA], double Bt[LG_NB], double ht[LG_NH]) {
 #pragma unroll
     for (int a = 0; a < 6; a++) {
 #pragma unroll
-        for (int b = 0; b <= a; b++) At[tri(a, b)] += cu[a] * cu[b] + cv[a] * cv[b];
+        for (int b = 0; b <= a; b++) At[tri(a, b)] = fma(cv[a], cv[b], fma(cu[a], cu[b], At[tri(a, b)]));
 #pragma unroll
         for (int s = 0; s < 9; s++) {
-            if (lg_in_u(s)) Bt[a * 9 + s] += cu[a] * q.ju[s];
-            if (lg_in_v(s)) Bt[a * 9 + s] += cv[a] * q.jv[s];
+            if (lg_in_u(s)) Bt[a * 9 + s] = fma(cu[a], q.ju[s], Bt[a * 9 + s]);
+            if (lg_in_v(s)) Bt[a * 9 + s] = fma(cv[a], q.jv[s], Bt[a * 9 + s]);
         }
-        ht[a] += cu[a] * q.eu + cv[a] * q.ev;
+        ht[a] = fma(cv[a], q.ev, fma(cu[a], q.eu, ht[a]));
+    }
+}
+// ... and its two halves, for register budgets that do not hold 81 sums beside the rows: pass A1 = B~ alone (84 multiply-adds, 54
+// sums), pass A2 = A~ and h~ (54 multiply-adds, 27 sums)
+CCAL_HD void lg_accum_A1(const LgPoint &q, const double cu[6], const double cv[6], double Bt[LG_NB]) {
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int s = 0; s < 9; s++) {
+            if (lg_in_u(s)) Bt[a * 9 + s] = fma(cu[a], q.ju[s], Bt[a * 9 + s]);
+            if (lg_in_v(s)) Bt[a * 9 + s] = fma(cv[a], q.jv[s], Bt[a * 9 + s]);
+        }
+}
+CCAL_HD void lg_accum_A2(const LgPoint &q, const double cu[6], const double cv[6], double At[LG_NA], double ht[LG_NH]) {
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+#pragma unroll
+        for (int b = 0; b <= a; b++) At[tri(a, b)] = fma(cv[a], cv[b], fma(cu[a], cu[b], At[tri(a, b)]));
+        ht[a] = fma(cv[a], q.ev, fma(cu[a], q.eu, ht[a]));
     }
 }
 
@@ -109,13 +128,13 @@ CCAL_HD void lg_accum_B(const LgPoint &q, double Ct[LG_NC], double gt[LG_NG], do
     for (int a = 0; a < 9; a++) {
 #pragma unroll
         for (int b = 0; b <= a; b++) {
-            if (lg_in_u(a) && lg_in_u(b)) Ct[tri(a, b)] += q.ju[a] * q.ju[b];
-            if (lg_in_v(a) && lg_in_v(b)) Ct[tri(a, b)] += q.jv[a] * q.jv[b];
+            if (lg_in_u(a) && lg_in_u(b)) Ct[tri(a, b)] = fma(q.ju[a], q.ju[b], Ct[tri(a, b)]);
+            if (lg_in_v(a) && lg_in_v(b)) Ct[tri(a, b)] = fma(q.jv[a], q.jv[b], Ct[tri(a, b)]);
         }
-        if (lg_in_u(a)) gt[a] += q.ju[a] * q.eu;
-        if (lg_in_v(a)) gt[a] += q.jv[a] * q.ev;
+        if (lg_in_u(a)) gt[a] = fma(q.ju[a], q.eu, gt[a]);
+        if (lg_in_v(a)) gt[a] = fma(q.jv[a], q.ev, gt[a]);
     }
-    ee += q.eu * q.eu + q.ev * q.ev;
+    ee = fma(q.ev, q.ev, fma(q.eu, q.eu, ee));
 }
 
 // T = blockdiag(K, I3) applied to the summed pose blocks of one image: A = T^T A~ T, B = T^T B~, h = T^T h~
