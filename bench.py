@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guides/MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 FP64_PEAK_TFLOPS = 78.6    # FP64 vector (= FP64 matrix) peak: 256 CUs x 128 flop/clk x 2.4 GHz
+FP64_MEASURED_TFLOPS = 60.0   # dense v_fma_f64 in every wave, measured on MI355X (profiles/r06_lane_group_probe.txt)
 # the clock these launches actually hold (s_memtime / s_memrealtime stamps, tools/stamps.py): 2.32 GHz with one wave per SIMD
 # (C3, profiles/r04_wave_stamps.json: 2.30-2.32), 2.1 GHz under sustained FP64 load (C5, profiles/r04_c5_pmc_utilisation_summary.json: SQ_WAVE_CYCLES over the waves' lifetime)
 CLOCK_GHZ_LATENCY, CLOCK_GHZ_FP64_LOAD, CLOCK_GHZ_PEAK = 2.32, 2.1, 2.4
@@ -814,6 +815,10 @@ def roofline_block(N_rank, P, K, sweep_us, n_timed, b2b_us, events_ms_per_step, 
         out["held_clock_ghz"] = CLOCK_GHZ_FP64_LOAD
         out["latency_floor_us_at_held_clock"] = KERNEL_BOUNDARY_US + flops / (held * 1e6)
         out["frac_of_floor_at_held_clock"] = out["latency_floor_us_at_held_clock"] / sweep_us if sweep_us > 0 else None
+        # what the vector unit of this chip sustains on dense independent v_fma_f64 in every wave (profiles/r06_lane_group_probe.txt,
+        # tools/lg_probe.hip: 57-62 TFLOP/s at the 2.0 GHz it then holds) -- a diagnostic beside the contract's peak, never instead of it
+        out["fp64_vector_rate_measured_tflops"] = FP64_MEASURED_TFLOPS
+        out["fp64_frac_of_measured_rate"] = tflops / FP64_MEASURED_TFLOPS
     else:
         out["held_clock_ghz"] = CLOCK_GHZ_LATENCY
     out["latency_floor_us"] = floor_us

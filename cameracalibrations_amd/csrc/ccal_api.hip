@@ -1565,9 +1565,12 @@ static bool fit_begin_merged(ccal_ctx *const *ctxs, const std::vector<int> &idx,
     // the terminating launch of an earlier ccal_fit -- is ordered in front of them: an event on that stream, waited for by c0's.  The
     // library knows when that can be the case for a stream it owns (join_needed; never in the steady state of ccal_fit_many, whose
     // contexts were last used by merged launches); a caller's stream (ccal_set_stream) is always joined.
+    std::vector<hipStream_t> joined;              // (ccal_calibrate_many puts all small calibrations on ONE stream: one join for all of them)
     for (int e = 1; e < m && ok; e++) {
         ccal_ctx *c = ctxs[idx[e]];
         if (c->stream == c0->stream || (!c->join_needed && c->stream == c->own_stream)) continue;
+        if (std::find(joined.begin(), joined.end(), c->stream) != joined.end()) continue;
+        joined.push_back(c->stream);
         if (c->ev_join == nullptr && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { ok = false; break; }
         if (hipEventRecord(c->ev_join, c->stream) != hipSuccess || hipStreamWaitEvent(c0->stream, c->ev_join, 0) != hipSuccess) ok = false;
     }
