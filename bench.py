@@ -1061,6 +1061,51 @@ def main():
         except BlockFailed as exc:    # (raised by every rank together)
             if rank == 0:
                 out["c5"] = {"error": str(exc)}
+    if extras and world > 1:
+        # Independent calibrations spread over the GPUs (a caller with many cameras: the loop around src/buildcalibrations.jl:12-26):
+        # every rank fits its own 32 C1-shaped calibrations per round with one ccal_fit_many, no exchange at all -- the way this path
+        # scales with GPUs when there are many small problems instead of one large one (hard part 3).
+        try:
+            def make_many():
+                from cameracalibrations_amd.solver import Solver as _S
+                ss = []
+                for i in range(32):
+                    wli = syn.named_workload("C1", seed_offset=100 * rank + i)
+                    si = _S(job.local_rank)
+                    si.set_problem(wli.obj, wli.n_images, wli.image_size, aspect=wli.aspect, flags=wli.flags, max_iter=CRITERIA[0], eps=CRITERIA[1])
+                    si.set_image_points(wli.img)
+                    ss.append(si)
+                for _ in range(3):
+                    cc_fit_many(ss)
+                return ss, wli.n_images * wli.n_points
+            from cameracalibrations_amd import fit_many as cc_fit_many
+            ss, corners_per_fit = job.together(make_many, "independent fits: set-up")
+            rounds_i = 20
+            job.barrier()
+            t0 = time.perf_counter()
+            ok_i, why_i, sweeps_i = True, "", 0
+            try:
+                for _ in range(rounds_i):
+                    cc_fit_many(ss)
+                sweeps_i = sum(int(si.result()["sweeps"]) for si in ss)
+            except Exception as exc:      # noqa: BLE001
+                ok_i, why_i = False, str(exc)
+            job.barrier()
+            dt_i = job.max_over_ranks(time.perf_counter() - t0)
+            if not job.all_agree(ok_i):
+                raise BlockFailed(why_i or "independent fits: a peer rank failed")
+            tot_sweeps = job.max_over_ranks(float(sweeps_i))      # (same shapes on every rank: the largest count stands for all)
+            for si in ss:
+                si.close()
+            if rank == 0:
+                out["independent_fits"] = {
+                    "what": "every rank fits its own 32 calibrations of the C1 shape (100 x 9x6, pinhole) per round with one ccal_fit_many (full fit: "
+                            "initialisation + LM, corners resident), no exchange between the ranks; barrier + max over ranks around 20 rounds",
+                    "fits_per_s": world * 32 * rounds_i / dt_i, "us_per_fit_whole_job": 1e6 * dt_i / (world * 32 * rounds_i),
+                    "corner_residuals_per_s": world * rounds_i * corners_per_fit * tot_sweeps / dt_i, "ranks": world, "scaling": "weak"}
+        except BlockFailed as exc:    # (raised by every rank together)
+            if rank == 0:
+                out["independent_fits"] = {"error": str(exc)}
     if extras and world > 1 and strong:
         # The same sharded fit over the other two transports (the headline takes --allreduce, by default the direct row
         # exchange): ncclAllReduce called by the library (RCCL; refuses ranks that share a device, so a rehearsal skips it)

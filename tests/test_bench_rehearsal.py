@@ -93,3 +93,6 @@ def test_bench_four_ranks_full_c3_rehearsal():
     t = d["transports"]
     assert set(t) == {"torch"} and t["torch"]["transport"].startswith("torch.distributed")
     assert abs(t["torch"]["rms_px"] - d["lm"]["rms_px"]) < 1e-9 and t["torch"]["iters"] == 4 and t["torch"]["ms_per_step"] > 0
+    # independent calibrations, 32 per rank and round, no exchange: the block that scales with GPUs when the problems are many and small
+    f = d["independent_fits"]
+    assert f["ranks"] == 4 and f["scaling"] == "weak" and f["fits_per_s"] > 1000 and f["corner_residuals_per_s"] > 0
