@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CCAL_VERSION 104 /* 0.1.4: ccal_fit_many, ccal_calibrate_many, ccal_detect_corners_many; 0.1.3: ccal_stats.sweep_form (was padding); 0.1.2: ccal_p2p_export2 / ccal_p2p_connect2, ccal_p2p_set_exchange mode 2 */
+#define CCAL_VERSION 105 /* 0.1.5: ccal_fit_many / ccal_calibrate_many return the UNION of the warning bits (was: the largest), merged launches join the participants' streams; 0.1.4: ccal_fit_many, ccal_calibrate_many, ccal_detect_corners_many; 0.1.3: ccal_stats.sweep_form (was padding); 0.1.2: ccal_p2p_export2 / ccal_p2p_connect2, ccal_p2p_set_exchange mode 2 */
 
 /* status codes */
 #define CCAL_OK            0

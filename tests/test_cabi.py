@@ -26,7 +26,7 @@ def test_header_symbols_exported(lib):
     assert declared == set(F.SIGNATURES), declared ^ set(F.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ccal_version() == 104
+    assert lib.ccal_version() == 105
 
 
 def test_no_cpu_fallback(lib):
