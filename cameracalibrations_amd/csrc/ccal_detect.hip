@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <map>
 #include <vector>
 
@@ -190,7 +191,7 @@ __device__ __forceinline__ double bilinear(const double *__restrict__ im, int ro
 // computed once per lane, not once per iteration.  (Staging the pixels around the peak in LDS was measured twice --
 // 32 x 32 with a per-sample fallback to memory, 48 x 48 with a wave-uniform choice per iteration: 51 and 37 us against
 // 28.  The kernel is bound by the arithmetic of its 4 x 529 bilinear samples per iteration, not by their loads.)
-__global__ __launch_bounds__(64) void k_det_subpix(const double *__restrict__ im, int rows, int cols,
+__global__ __launch_bounds__(64) void k_det_subpix(const double *__restrict__ im, const double *__restrict__ resp, int rows, int cols,
                                                     const Peak *__restrict__ list, int n, double *__restrict__ out,
                                                     unsigned int *__restrict__ done, unsigned long long *__restrict__ h_flag,
                                                     unsigned long long *__restrict__ d_seq) {
@@ -269,7 +270,17 @@ __global__ __launch_bounds__(64) void k_det_subpix(const double *__restrict__ im
     // the nearest other peak -- graded, or OpenCV's 11 px for peaks with no neighbour within 40 px -- were measured in round 6 and are
     // worse: the graded one loses a sheared board, and on heavily blurred 2-megapixel boards the wide bound admits refinements 12 px
     // off (mean corner error 1.35 px against 0.39 with the fixed 2 px): profiles/r06_detector_probe.txt
-    if (fabs(qr - pr) > SUBPIX_MAX_SHIFT || fabs(qc - pc) > SUBPIX_MAX_SHIFT) { qr = pr; qc = pc; }
+    if (fabs(qr - pr) > SUBPIX_MAX_SHIFT || fabs(qc - pc) > SUBPIX_MAX_SHIFT) {
+        // ... at the sub-pixel position of the response peak itself (round 6): per axis the vertex of the parabola through the peak's
+        // response and its two neighbours' (a local maximum: the vertex lies within half a pixel), instead of the integer pixel
+        qr = pr; qc = pc;
+        if (resp != nullptr) {
+            const double *rp = resp + (size_t)pri * cols + pci;
+            const double r0 = rp[0], dr = rp[-cols] - 2.0 * r0 + rp[cols], dc = rp[-1] - 2.0 * r0 + rp[1];
+            if (dr < 0.0) qr += fmin(0.5, fmax(-0.5, 0.5 * (rp[-cols] - rp[cols]) / dr));
+            if (dc < 0.0) qc += fmin(0.5, fmax(-0.5, 0.5 * (rp[-1] - rp[1]) / dc));
+        }
+    }
     if (lane == 0) {
         out[2 * i] = qr; out[2 * i + 1] = qc;
         // `out` is pinned host memory: the last workgroup to finish raises the completion word the host spins on
@@ -662,7 +673,9 @@ int Detector::mid(hipStream_t stream, int n1, int n2, double *stage_out, std::st
     std::sort(peaks.begin(), peaks.end(), [&](const Peak &x, const Peak &y) { return x.r != y.r ? x.r < y.r : x.c < y.c; });
     // raster order; the sub-pixel kernel reads the list from, and writes the refined corners to, the pinned block
     memcpy(h_peaks, peaks.data(), sizeof(Peak) * n);
-    hipLaunchKernelGGL(k_det_subpix, dim3(n), dim3(64), 0, stream, (const double *)d_img, cur_rows, cur_cols, (const Peak *)h_peaks, n, h_sub,
+    static const bool no_parabola = getenv("CCAL_DET_NO_PARABOLA") != nullptr;     // (experiments: reverted refinements fall back to the integer peak)
+    hipLaunchKernelGGL(k_det_subpix, dim3(n), dim3(64), 0, stream, (const double *)d_img, no_parabola ? (const double *)nullptr : (const double *)d_R,
+                       cur_rows, cur_cols, (const Peak *)h_peaks, n, h_sub,
                        reinterpret_cast<unsigned int *>(d_misc) + 8, h_flag, reinterpret_cast<unsigned long long *>(d_misc) + 8);
     if (hipGetLastError() != hipSuccess) { seq_resync = true; err = "k_det_subpix launch failed"; return -5; }
     ++pin_seq;

@@ -26,6 +26,8 @@ Coordinates: the image is the Julia matrix img[row, col]; a corner is RowCol = (
 pixel-centre coordinates, which is what OpenCV returns as (x, y) for the transposed view it is
 handed (reference src/detect_fit.jl:7).
 """
+import os
+
 import numpy as np
 
 SIGMA = 1.0
@@ -111,7 +113,7 @@ def _bilinear(im, rr, cc):
             + fr * fc * im[r1, c1])
 
 
-def corner_subpix(im, pts):
+def corner_subpix(im, pts, resp=None):
     """[OCV-K cornerSubPix]: iterate q <- q + G^-1 b over a Gaussian-weighted (2w+1)^2 window of
     image gradients sampled bilinearly around q."""
     h, w = im.shape
@@ -144,7 +146,18 @@ def corner_subpix(im, pts):
             if err <= SUBPIX_EPS * SUBPIX_EPS:
                 break
         if abs(qr - pr) > SUBPIX_MAX_SHIFT or abs(qc - pc) > SUBPIX_MAX_SHIFT:
+            # not believed: the response peak stands -- at its own sub-pixel position (per axis the vertex of the parabola through the
+            # peak's response and its two neighbours'), not at the integer pixel
             qr, qc = float(pr), float(pc)
+            if resp is not None and not os.environ.get("CCAL_DET_NO_PARABOLA"):
+                r, c = int(pr), int(pc)
+                r0 = resp[r, c]
+                dr = resp[r - 1, c] - 2.0 * r0 + resp[r + 1, c]
+                dc = resp[r, c - 1] - 2.0 * r0 + resp[r, c + 1]
+                if dr < 0.0:
+                    qr += min(0.5, max(-0.5, 0.5 * (resp[r - 1, c] - resp[r + 1, c]) / dr))
+                if dc < 0.0:
+                    qc += min(0.5, max(-0.5, 0.5 * (resp[r, c - 1] - resp[r, c + 1]) / dc))
         out[i] = (qr, qc)
     return out
 
@@ -285,6 +298,6 @@ def detect_corners(im, n_corners):
     pts, resp = peaks(R)
     if len(pts) < n_corners[0] * n_corners[1]:
         return None
-    pts = corner_subpix(im, pts)
+    pts = corner_subpix(im, pts, R)
     pts, resp = merge_close(pts, resp)
     return order_grid(pts, resp, n_corners[0], n_corners[1], im)

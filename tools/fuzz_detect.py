@@ -81,12 +81,13 @@ for case in range(args.cases):
         # 1e-13 px on boards both find), stage by stage
         from oracle import detect_oracle as D
         imf = np.asarray(img, dtype=np.float64)
-        pts, resp = D.peaks(D.chess_response(D.blur(imf)))
+        Rm = D.chess_response(D.blur(imf))
+        pts, resp = D.peaks(Rm)
         near = sum(1 for t in truth if len(pts) and np.linalg.norm(pts - t, axis=1).min() < 2.0)
         if near < n1 * n2:
             why = f"peak list: {near} of {n1 * n2} true corners have a response peak within 2 px ({len(pts)} peaks in all)"
         else:
-            p2, r2 = D.merge_close(D.corner_subpix(imf, pts), resp)
+            p2, r2 = D.merge_close(D.corner_subpix(imf, pts, Rm), resp)
             kept = sum(1 for t in truth if np.linalg.norm(p2 - t, axis=1).min() < 1.5)
             if kept < n1 * n2:
                 why = (f"sub-pixel refinement: every corner has its response peak, but {n1 * n2 - kept} of them leave it by more than 1.5 px under "
