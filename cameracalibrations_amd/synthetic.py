@@ -179,3 +179,36 @@ def generate_checkerboard(n_corners, n):
     imgl = np.kron(pad.astype(np.float64), np.ones((n, n)))
     xys = np.array([(n * ii - 0.5, n * jj - 0.5) for jj in range(n2 + 1, 1, -1) for ii in range(n1 + 1, 1, -1)])
     return xys, imgl * 255.0
+
+
+def render_board_view(n_corners, rvec, tvec, size=(480, 640), f=600.0, blur_sigma=0.0, noise=0.0, rng=None, supersample=3):
+    """A perspective view of an n1 x n2-corner checkerboard (unit squares, one-square margin, dark squares 30 / bright 225) seen by a
+    pinhole camera of focal length f (pixel (row, col) = (x_cv, y_cv) of the reference convention) under pose (rvec, tvec): -> uint8 image
+    (rows, cols) and the projected true corners (P, 2), first corner dimension fastest.  Input generator only (tools/fuzz_detect.py, tests:
+    perspective, blur and noise beyond the reference's axis-aligned synthetic boards); the detector never sees it."""
+    n1, n2 = n_corners
+    H, W = size
+    R = rodrigues(np.asarray(rvec, dtype=np.float64)[None])[0]
+    tv = np.asarray(tvec, dtype=np.float64)
+    ss = int(supersample)
+    rr, cc = np.meshgrid((np.arange(H * ss) + 0.5) / ss - 0.5, (np.arange(W * ss) + 0.5) / ss - 0.5, indexing="ij")
+    d = np.stack([(rr - (H - 1) / 2) / f, (cc - (W - 1) / 2) / f, np.ones_like(rr)], axis=-1)
+    n = R[:, 2]
+    t = (tv @ n) / (d @ n)
+    b = (d * t[..., None] - tv) @ R                # board coordinates (squares), z ~ 0
+    u, v = b[..., 0], b[..., 1]
+    inside = (u > -1) & (u < n1) & (v > -1) & (v < n2) & (t > 0)
+    dark = ((np.floor(u).astype(int) + np.floor(v).astype(int)) % 2) == 0
+    img = np.where(inside, np.where(dark, 30.0, 225.0), 225.0)
+    img = img.reshape(H, ss, W, ss).mean(axis=(1, 3))
+    if blur_sigma > 0:
+        kr = max(4, int(np.ceil(3 * blur_sigma)))
+        k = np.exp(-0.5 * (np.arange(-kr, kr + 1) / blur_sigma) ** 2)
+        k /= k.sum()
+        img = np.apply_along_axis(lambda m: np.convolve(m, k, mode="same"), 0, img)
+        img = np.apply_along_axis(lambda m: np.convolve(m, k, mode="same"), 1, img)
+    if rng is not None or noise > 0:               # (a caller's generator is always advanced: the draws of tools/fuzz_detect.py stay what they were)
+        img = img + (rng or np.random.default_rng(0)).normal(0, noise, img.shape)
+    pc = board_template((n1, n2)) @ R.T + tv
+    truth = np.stack([f * pc[:, 0] / pc[:, 2] + (H - 1) / 2, f * pc[:, 1] / pc[:, 2] + (W - 1) / 2], axis=1)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8), truth

@@ -48,6 +48,50 @@ def test_oracle_rejects_wrong_board():
     assert D.detect_corners(np.full((200, 200), 128, dtype=np.uint8), (5, 8)) is None
 
 
+# a strongly sheared view (draw 40 of tools/fuzz_detect.py --seed 6 --max-tilt 0.9: profiles/r06_detector_probe.txt): five of its 28 corners
+# are pulled more than 2 px off their response peak by a neighbouring edge inside cornerSubPix's window and are reverted
+_SHEARED = dict(n_corners=(7, 4), rvec=[-0.8590072086231154, -0.8978087384501281, -0.6208911503178958],
+                tvec=[-3.0475641056510874, -0.012294546882449131, 10.423637389537959], blur_sigma=0.8)
+
+
+def test_oracle_reverted_refinements_take_the_response_peaks_parabola():
+    """A refinement that leaves its response peak by more than 2 px falls back to the peak's own sub-pixel position: per axis the vertex of
+    the parabola through the peak's response and its two neighbours'.  Exact on a response that IS a parabola; within half a pixel of the
+    integer peak always; and the sheared board is found with it, every corner within 1.5 px of the projected truth."""
+    # (a) an X corner 6.5 px beside the point, inside cornerSubPix's window: the iteration runs to it -> more than 2 px -> reverted
+    rr, cc = np.meshgrid(np.arange(64.0), np.arange(64.0), indexing="ij")
+    im = np.where((rr < 30.5) ^ (cc < 38.5), 200.0, 40.0)
+    resp = -((rr - 30.3) ** 2 + 2.0 * (cc - 31.8) ** 2)
+    out = D.corner_subpix(im, np.array([[30, 32]]), resp)
+    assert np.allclose(out[0], (30.3, 31.8), atol=1e-12)
+    assert np.array_equal(D.corner_subpix(im, np.array([[30, 32]]), None)[0], (30.0, 32.0))      # without a response: the integer peak
+    # (b) the sheared view
+    img, truth = syn.render_board_view(**_SHEARED)
+    imf = img.astype(np.float64)
+    R = D.chess_response(D.blur(imf))
+    pts, _ = D.peaks(R)
+    a, b = D.corner_subpix(imf, pts, None), D.corner_subpix(imf, pts, R)
+    moved = np.any(a != b, axis=1)
+    assert moved.sum() >= 3 and np.abs(a - b).max() <= 0.5 and np.array_equal(a[moved], np.rint(a[moved]))
+    res = D.detect_corners(img, _SHEARED["n_corners"])
+    assert res is not None
+    n1, n2 = _SHEARED["n_corners"]
+    T = truth.reshape(n2, n1, 2)
+    assert min(np.linalg.norm(res - c.reshape(-1, 2), axis=1).max() for c in (T, T[::-1, ::-1], T[::-1], T[:, ::-1])) < 1.5
+
+
+@pytest.mark.gpu
+def test_gpu_reverted_refinements_match_the_oracle():
+    """The kernel's fallback branch (k_det_subpix: parabola through the response peak) against the oracle's on the sheared view."""
+    from cameracalibrations_amd.detect import detect_corners
+    img, _ = syn.render_board_view(**_SHEARED)
+    n1, n2 = _SHEARED["n_corners"]
+    want = D.detect_corners(img, (n1, n2))
+    got = detect_corners(img, (n1, n2))
+    assert want is not None and got is not None
+    assert np.abs(got.transpose(1, 0, 2).reshape(-1, 2) - want).max() < 1e-6
+
+
 # ------------------------------------------------------------------------------------------ GPU
 @pytest.mark.gpu
 def test_gpu_stages_match_oracle():

@@ -32,32 +32,7 @@ Z0, Z1 = (float(v) for v in args.zrange.split(","))
 
 
 def render(n1, n2, rv, tv, blur_sigma, noise):
-    R = syn.rodrigues(rv[None])[0]
-    ss = 3
-    rr, cc = np.meshgrid((np.arange(H * ss) + 0.5) / ss - 0.5, (np.arange(W * ss) + 0.5) / ss - 0.5, indexing="ij")
-    # pixel (row, col) == (x_cv, y_cv) of the reference convention: x = row, y = col
-    d = np.stack([(rr - (H - 1) / 2) / f, (cc - (W - 1) / 2) / f, np.ones_like(rr)], axis=-1)
-    n = R[:, 2]
-    t = (tv @ n) / (d @ n)
-    Xc = d * t[..., None] - tv
-    b = Xc @ R                                   # board coordinates (squares), z ~ 0
-    u, v = b[..., 0], b[..., 1]
-    inside = (u > -1) & (u < n1) & (v > -1) & (v < n2) & (t > 0)
-    dark = ((np.floor(u).astype(int) + np.floor(v).astype(int)) % 2) == 0
-    img = np.where(inside, np.where(dark, 30.0, 225.0), 225.0)
-    # white margin of half a square around the board
-    img = img.reshape(H, ss, W, ss).mean(axis=(1, 3))
-    if blur_sigma > 0:
-        kr = max(4, int(np.ceil(3 * blur_sigma)))
-        k = np.exp(-0.5 * (np.arange(-kr, kr + 1) / blur_sigma) ** 2)
-        k /= k.sum()
-        img = np.apply_along_axis(lambda m: np.convolve(m, k, mode="same"), 0, img)
-        img = np.apply_along_axis(lambda m: np.convolve(m, k, mode="same"), 1, img)
-    img = img + rng.normal(0, noise, img.shape)
-    obj = syn.board_template((n1, n2))
-    pc = obj @ R.T + tv
-    truth = np.stack([f * pc[:, 0] / pc[:, 2] + (H - 1) / 2, f * pc[:, 1] / pc[:, 2] + (W - 1) / 2], axis=1)
-    return np.clip(np.rint(img), 0, 255).astype(np.uint8), truth
+    return syn.render_board_view((n1, n2), rv, tv, size=(H, W), f=f, blur_sigma=blur_sigma, noise=noise, rng=rng)
 
 
 found, good, n_cases, lost = 0, 0, 0, {}
