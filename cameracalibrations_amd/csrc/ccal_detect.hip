@@ -6,16 +6,20 @@
 // reference's: every corner within 1 px of the analytic position on the synthetic boards of
 // test/runtests.jl:6-43 and within 1 px of test/example/corners.json on the example PNGs
 // (test/runtests.jl:53-65), in OpenCV's corner order.  The sub-pixel stage restates the published
-// cornerSubPix iteration ([OCV-K], window (11,11), criteria (30, 1e-3)).  The algorithm is spelled
-// out in oracle/detect_oracle.py, which the GPU tests compare against stage by stage.
+// cornerSubPix iteration ([OCV-K], window (11,11), criteria (30, 1e-3)) -- with two deviations that make it
+// more accurate than the fixed-window original on foreshortened boards (profiles/r06_detector_probe.txt):
+// the window of a peak ends short of the half-way point to the nearest other response peak (OpenCV's 11
+// from 27 px of spacing on), and a refinement that leaves its peak by more than 2 px falls back to the
+// response peak's own sub-pixel position.  The algorithm is spelled out in oracle/detect_oracle.py, which
+// the GPU tests compare against stage by stage.
 //
 // Device stages (FP64 throughout; images are small, agreement with the oracle matters more):
 //   k_det_load   strided uint8 -> canonical [rows][cols] double
 //   k_det_blur   9-tap Gaussian, sigma 1, replicated borders (columns pass, then rows pass)
 //   k_det_chess  ChESS response on the radius-5 ring + global maximum (atomic max on the bits)
 //   k_det_peaks  13 x 13 non-maximum suppression, raster tie-break, threshold 0.15 max -> list
-//   k_det_subpix one wavefront per peak: Gaussian-weighted gradient normal equations over the
-//                23 x 23 window sampled bilinearly, wave butterfly sums, <= 30 iterations
+//   k_det_subpix one wavefront per peak: Gaussian-weighted gradient normal equations over the peak's
+//                (2 win + 1)^2 window (win <= 11) sampled bilinearly, wave butterfly sums, <= 30 iterations
 // Host: merge of coincident peaks, lattice growth and ordering (tens of points).
 #include <hip/hip_runtime.h>
 
@@ -41,7 +45,9 @@ constexpr int BLUR_R = 4;
 constexpr int BORDER = 7;
 constexpr int NMS_R = 6;
 constexpr double REL_THRESHOLD = 0.15;
-constexpr int SUBPIX_WIN = 11;
+constexpr int SUBPIX_WIN = 11;       // OpenCV's / the reference's window (11, 11): a HALF size (23 x 23 samples)
+constexpr int SUBPIX_MIN_WIN = 3;
+constexpr double SUBPIX_WIN_FRAC = 0.45;  // window half-size = floor(this x distance to the nearest other peak) - 1, clamped to [3, 11]
 constexpr int SUBPIX_ITERS = 30;
 constexpr double SUBPIX_EPS = 1e-3;
 constexpr double SUBPIX_MAX_SHIFT = 2.0;
@@ -201,14 +207,19 @@ __global__ __launch_bounds__(64) void k_det_subpix(const double *__restrict__ im
     auto bil = [&](double rr, double cc) -> double { return bilinear(im, rows, cols, rr, cc); };
     const double pr = pri, pc = pci;
     double qr = pr, qc = pc;
-    constexpr int W = 2 * SUBPIX_WIN + 1;
-    constexpr int NPASS = (W * W + 63) / 64;
+    // this peak's window half-size (host: subpix_window of its distance to the nearest other peak; OpenCV's 11 unless a neighbouring
+    // corner would sit inside the window) -- wave-uniform.  Sample k of the (2 win + 1)^2 window: row / column offsets and weight, once
+    const int win = min(SUBPIX_WIN, max(SUBPIX_MIN_WIN, (int)list[i].v));
+    const int W = 2 * win + 1, WW = W * W;
+    constexpr int NPASS = ((2 * SUBPIX_WIN + 1) * (2 * SUBPIX_WIN + 1) + 63) / 64;
     double wgt[NPASS];
+    int wis[NPASS], wjs[NPASS];
 #pragma unroll
     for (int t = 0; t < NPASS; t++) {
         const int k = lane + 64 * t;
-        const int wi = k / W - SUBPIX_WIN, wj = k % W - SUBPIX_WIN;       // row, col offsets
-        wgt[t] = exp(-(double)(wi * wi) / (double)(SUBPIX_WIN * SUBPIX_WIN)) * exp(-(double)(wj * wj) / (double)(SUBPIX_WIN * SUBPIX_WIN));
+        const int wi = k / W - win, wj = k % W - win;       // row, col offsets
+        wis[t] = wi; wjs[t] = wj;
+        wgt[t] = k < WW ? exp(-(double)(wi * wi) / (double)(win * win)) * exp(-(double)(wj * wj) / (double)(win * win)) : 0.0;
     }
     for (int it = 0; it < SUBPIX_ITERS; it++) {
         double a = 0, b = 0, c = 0, bb1 = 0, bb2 = 0;
@@ -216,8 +227,8 @@ __global__ __launch_bounds__(64) void k_det_subpix(const double *__restrict__ im
         // from the image border (no sample coordinate is clamped) the two central differences are bilinear blends of
         // grid differences over a 4 x 4 neighbourhood -- 12 loads and ~25 flops per sample instead of four full
         // bilinear evaluations (16 loads, four times the clamps / floors / weights).  Same quantity, different rounding
-        // order; estimates within SUBPIX_WIN + 2 px of the border keep the clamped evaluation.
-        const bool interior = qr >= SUBPIX_WIN + 2 && qr < rows - SUBPIX_WIN - 3 && qc >= SUBPIX_WIN + 2 && qc < cols - SUBPIX_WIN - 3;
+        // order; estimates within win + 2 px of the border keep the clamped evaluation.
+        const bool interior = qr >= win + 2 && qr < rows - win - 3 && qc >= win + 2 && qc < cols - win - 3;
         if (interior) {
             const int r0 = (int)floor(qr), c0 = (int)floor(qc);
             const double fr = qr - r0, fc = qc - c0;
@@ -225,8 +236,8 @@ __global__ __launch_bounds__(64) void k_det_subpix(const double *__restrict__ im
 #pragma unroll
             for (int t = 0; t < NPASS; t++) {
                 const int k = lane + 64 * t;
-                if (k < W * W) {
-                    const int wi = k / W - SUBPIX_WIN, wj = k % W - SUBPIX_WIN;
+                if (k < WW) {
+                    const int wi = wis[t], wj = wjs[t];
                     const double m = wgt[t];
                     const double *p = im + (size_t)(r0 + wi) * cols + (c0 + wj);     // I[0][0] of the neighbourhood
                     const double *pm = p - cols, *p1 = p + cols, *p2 = p1 + cols;
@@ -243,8 +254,8 @@ __global__ __launch_bounds__(64) void k_det_subpix(const double *__restrict__ im
 #pragma unroll
             for (int t = 0; t < NPASS; t++) {
                 const int k = lane + 64 * t;
-                if (k < W * W) {
-                    const int wi = k / W - SUBPIX_WIN, wj = k % W - SUBPIX_WIN;
+                if (k < WW) {
+                    const int wi = wis[t], wj = wjs[t];
                     const double m = wgt[t];
                     const double gc = bil(qr + wi, qc + wj + 1) - bil(qr + wi, qc + wj - 1);
                     const double gr = bil(qr + wi + 1, qc + wj) - bil(qr + wi - 1, qc + wj);
@@ -673,6 +684,26 @@ int Detector::mid(hipStream_t stream, int n1, int n2, double *stage_out, std::st
     std::sort(peaks.begin(), peaks.end(), [&](const Peak &x, const Peak &y) { return x.r != y.r ? x.r < y.r : x.c < y.c; });
     // raster order; the sub-pixel kernel reads the list from, and writes the refined corners to, the pinned block
     memcpy(h_peaks, peaks.data(), sizeof(Peak) * n);
+    // The kernel's copy of an entry carries the peak's WINDOW half-size instead of its response (which stays in `peaks` for the merge):
+    // floor(0.45 d) - 1 for a peak whose nearest other response peak is d pixels away, at least 3, at most OpenCV's 11 (from d = 27 px on).
+    // A neighbouring corner's edges inside the 23 x 23 window pull the estimate by 1.3-2.2 px on strongly sheared lattices, so the window
+    // ends short of the half-way point to the nearest neighbour (factors 0.4 ... 0.7 measured: profiles/r06_detector_probe.txt).  In
+    // raster order only rows closer than the best distance so far need a look.
+    static const bool fixed_win = getenv("CCAL_DET_FIXED_WIN") != nullptr;     // (experiments: the 11 for every peak)
+    static const double frac = getenv("CCAL_DET_WIN_FRAC") ? atof(getenv("CCAL_DET_WIN_FRAC")) : SUBPIX_WIN_FRAC;
+    for (int i = 0; i < n; i++) {
+        double best = 1e300;
+        for (int j = i + 1; j < n && (double)(peaks[j].r - peaks[i].r) * (peaks[j].r - peaks[i].r) < best; j++) {
+            const double dr = peaks[j].r - peaks[i].r, dc = peaks[j].c - peaks[i].c;
+            best = std::min(best, dr * dr + dc * dc);
+        }
+        for (int j = i - 1; j >= 0 && (double)(peaks[i].r - peaks[j].r) * (peaks[i].r - peaks[j].r) < best; j--) {
+            const double dr = peaks[j].r - peaks[i].r, dc = peaks[j].c - peaks[i].c;
+            best = std::min(best, dr * dr + dc * dc);
+        }
+        const double half = floor(sqrt(best) * frac) - 1.0;
+        h_peaks[i].v = fixed_win ? (double)SUBPIX_WIN : std::min((double)SUBPIX_WIN, std::max((double)SUBPIX_MIN_WIN, half));
+    }
     static const bool no_parabola = getenv("CCAL_DET_NO_PARABOLA") != nullptr;     // (experiments: reverted refinements fall back to the integer peak)
     hipLaunchKernelGGL(k_det_subpix, dim3(n), dim3(64), 0, stream, (const double *)d_img, no_parabola ? (const double *)nullptr : (const double *)d_R,
                        cur_rows, cur_cols, (const Peak *)h_peaks, n, h_sub,

@@ -38,6 +38,8 @@ BORDER = 7
 NMS_R = 6
 REL_THRESHOLD = 0.15
 SUBPIX_WIN = 11
+SUBPIX_MIN_WIN = 3
+SUBPIX_WIN_FRAC = float(os.environ.get("CCAL_DET_WIN_FRAC", "0.45"))     # (the environment variable: experiments only)
 SUBPIX_ITERS = 30
 SUBPIX_EPS = 1e-3
 SUBPIX_MAX_SHIFT = 2.0    # a refinement that leaves its response peak by more than this is not believed: the peak stands (OpenCV: the half window, 11)
@@ -113,16 +115,30 @@ def _bilinear(im, rr, cc):
             + fr * fc * im[r1, c1])
 
 
+def subpix_windows(pts):
+    """Half-size of cornerSubPix's window per response peak: floor(0.45 d) - 1 for a peak whose nearest other peak is d pixels away, at
+    least 3 and at most OpenCV's 11 (the reference's (11, 11), src/detect_fit.jl:19; reached from d = 27 px on).  A neighbouring corner's
+    edges inside the window pull the estimate -- 1.3-2.2 px on strongly sheared lattices with the fixed window -- so the window ends short of
+    the half-way point to the nearest neighbour (factors 0.4 ... 0.7 measured: profiles/r06_detector_probe.txt)."""
+    p = np.asarray(pts, dtype=np.float64)
+    if len(p) < 2:
+        return np.full(len(p), SUBPIX_WIN, dtype=int)
+    d2 = ((p[:, None, :] - p[None, :, :]) ** 2).sum(axis=2)
+    np.fill_diagonal(d2, np.inf)
+    return np.clip(np.floor(np.sqrt(d2.min(axis=1)) * SUBPIX_WIN_FRAC).astype(int) - 1, SUBPIX_MIN_WIN, SUBPIX_WIN)
+
+
 def corner_subpix(im, pts, resp=None):
     """[OCV-K cornerSubPix]: iterate q <- q + G^-1 b over a Gaussian-weighted (2w+1)^2 window of
     image gradients sampled bilinearly around q."""
     h, w = im.shape
-    win = SUBPIX_WIN
-    m1 = np.exp(-(np.arange(-win, win + 1) ** 2) / float(win * win))
-    mask = np.outer(m1, m1)
-    off = np.arange(-win, win + 1, dtype=np.float64)
     out = np.array(pts, dtype=np.float64)
+    wins = subpix_windows(pts) if not os.environ.get("CCAL_DET_FIXED_WIN") else np.full(len(out), SUBPIX_WIN, dtype=int)
     for i, (pr, pc) in enumerate(pts):
+        win = int(wins[i])
+        m1 = np.exp(-(np.arange(-win, win + 1) ** 2) / float(win * win))
+        mask = np.outer(m1, m1)
+        off = np.arange(-win, win + 1, dtype=np.float64)
         qr, qc = float(pr), float(pc)
         for _ in range(SUBPIX_ITERS):
             rr = qr + np.arange(-win - 1, win + 2)[:, None] + 0 * np.arange(-win - 1, win + 2)[None, :]
