@@ -329,9 +329,12 @@ bool order_grid(const std::vector<P2> &pts, const std::vector<double> &resp, int
         const int r = std::min(std::max((int)std::nearbyint(qr), 0), rows - 1), c = std::min(std::max((int)std::nearbyint(qc), 0), cols - 1);
         return (double)gray[(long long)r * sr + (long long)c * sc];
     };
-    auto edge_contrast = [&](const P2 &p, const P2 &v) {
+    // w != nullptr (a window's validation, where the lattice is known): the two samples sit a quarter of the OTHER axis' step w to either
+    // side instead of a quarter of the segment's length along its normal -- under strong shear (axes 30 degrees apart) the squares beside
+    // an edge are slivers that the perpendicular leaves
+    auto edge_contrast = [&](const P2 &p, const P2 &v, const P2 *w = nullptr) {
         const double ln = std::hypot(v.r, v.c);
-        const double nr = -v.c / ln, nc = v.r / ln;
+        const double nr = w ? w->r / ln : -v.c / ln, nc = w ? w->c / ln : v.r / ln;
         const double mr = p.r + 0.5 * v.r, mc = p.c + 0.5 * v.c;
         return std::fabs(px(mr + 0.25 * ln * nr, mc + 0.25 * ln * nc) - px(mr - 0.25 * ln * nr, mc - 0.25 * ln * nc));
     };
@@ -412,14 +415,25 @@ bool order_grid(const std::vector<P2> &pts, const std::vector<double> &resp, int
                 for (int j = 0; j < m2; j++)
                     for (int k = 0; k < 4; k++) {
                         const int i2 = i + di[k], j2 = j + dj[k];
+                        // the other axis' step at this point (towards the inside of the window where there is no neighbour outside)
+                        const int io = di[k] != 0 ? i : (i + 1 < m1 ? i + 1 : i - 1), jo = di[k] != 0 ? (j + 1 < m2 ? j + 1 : j - 1) : j;
+                        const P2 ww{at(io, jo).r - at(i, j).r, at(io, jo).c - at(i, j).c};
                         P2 vv;
                         if (i2 >= 0 && i2 < m1 && j2 >= 0 && j2 < m2) {
                             if (di[k] + dj[k] < 0) continue;       // (each inner segment once)
                             vv = {at(i2, j2).r - at(i, j).r, at(i2, j2).c - at(i, j).c};
                         } else {
-                            vv = {at(i, j).r - at(i - di[k], j - dj[k]).r, at(i, j).c - at(i - di[k], j - dj[k]).c};   // extrapolated outwards
+                            // extrapolated outwards; under perspective consecutive steps along a lattice line form a geometric
+                            // progression: the step beyond the border is the last one times the ratio of the last two
+                            vv = {at(i, j).r - at(i - di[k], j - dj[k]).r, at(i, j).c - at(i - di[k], j - dj[k]).c};
+                            const int i3 = i - 2 * di[k], j3 = j - 2 * dj[k];
+                            if (i3 >= 0 && i3 < m1 && j3 >= 0 && j3 < m2) {
+                                const P2 prev{at(i - di[k], j - dj[k]).r - at(i3, j3).r, at(i - di[k], j - dj[k]).c - at(i3, j3).c};
+                                const double ratio = std::min(1.5, std::max(0.5, std::hypot(vv.r, vv.c) / std::hypot(prev.r, prev.c)));
+                                vv = {vv.r * ratio, vv.c * ratio};
+                            }
                         }
-                        cs.push_back(edge_contrast(at(i, j), vv));
+                        cs.push_back(edge_contrast(at(i, j), vv, &ww));
                     }
             std::vector<double> srt(cs);
             std::sort(srt.begin(), srt.end());

@@ -199,12 +199,14 @@ def order_grid(pts, resp, n1, n2, im):
         q = int(np.argmin(((pts - p) ** 2).sum(1)))
         return q, float(np.sqrt(((pts[q] - p) ** 2).sum()))
 
-    def edge_contrast(p, v):
+    def edge_contrast(p, v, w=None):
         """|gray difference| across the segment p -> p + v at its midpoint, a quarter of its length to either side: a lattice
         AXIS neighbour's segment runs along the edge between a dark and a bright square (large), a diagonal neighbour's through
-        the middle of one square and a two-step neighbour's midpoint is itself a corner (both ~0)"""
+        the middle of one square and a two-step neighbour's midpoint is itself a corner (both ~0).  w (a window's validation, where
+        the lattice is known): the two samples sit a quarter of the OTHER axis' step w to either side instead -- under strong shear
+        (axes 30 degrees apart) the squares beside an edge are slivers that the perpendicular leaves"""
         ln = float(np.hypot(v[0], v[1]))
-        n = np.array([-v[1], v[0]]) / ln
+        n = np.array([-v[1], v[0]]) / ln if w is None else np.asarray(w, dtype=np.float64) / ln
         mid = p + 0.5 * v
 
         def px(q):
@@ -224,13 +226,22 @@ def order_grid(pts, resp, n1, n2, im):
             for j in range(m2_):
                 for di, dj in ((1, 0), (-1, 0), (0, 1), (0, -1)):
                     i2, j2 = i + di, j + dj
+                    # the other axis' step at this point (towards the inside of the window where there is no neighbour outside)
+                    io, jo = (i, j + 1 if j + 1 < m2_ else j - 1) if di != 0 else (i + 1 if i + 1 < m1_ else i - 1, j)
+                    w = g[io, jo] - g[i, j]
                     if 0 <= i2 < m1_ and 0 <= j2 < m2_:
                         if di + dj < 0:
                             continue                      # (each inner segment once)
                         v = g[i2, j2] - g[i, j]
                     else:
-                        v = g[i, j] - g[i - di, j - dj]    # extrapolated outwards
-                    cs.append(edge_contrast(g[i, j], v))
+                        # extrapolated outwards; under perspective consecutive steps along a lattice line form a geometric
+                        # progression: the step beyond the border is the last one times the ratio of the last two
+                        v = g[i, j] - g[i - di, j - dj]
+                        i3, j3 = i - 2 * di, j - 2 * dj
+                        if 0 <= i3 < m1_ and 0 <= j3 < m2_:
+                            prev = g[i - di, j - dj] - g[i3, j3]
+                            v = v * min(1.5, max(0.5, float(np.hypot(v[0], v[1]) / np.hypot(prev[0], prev[1]))))
+                    cs.append(edge_contrast(g[i, j], v, w))
         cs = np.array(cs)
         return bool(cs.min() >= 0.25 * np.median(cs))
 
