@@ -14,6 +14,8 @@ from cameracalibrations_amd import distributed as D
 from cameracalibrations_amd import synthetic as syn
 from oracle import oracle as orc
 
+from _spawn import spawn_ranks
+
 LAM = 1e-3
 
 
@@ -58,12 +60,9 @@ def _worker(rank, world, port, out):
 
 
 def test_sharded_step_equals_dense_step():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    spawn_ranks(_worker, lambda port: (2, port, out), 2, out)
     assert set(out.keys()) == {0, 1}
     d0, e0, span0 = out[0]
     d1, e1, span1 = out[1]
@@ -109,12 +108,9 @@ def _handle_worker(rank, world, port, out):
 def test_handle_exchange_helpers_world2():
     """The bootstrap of both native transports: every rank's 64-byte inbox handle in rank order
     (direct exchange) and rank 0's 128-byte id on every rank (RCCL)."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_handle_worker, args=(2, port, out), nprocs=2, join=True)
+    spawn_ranks(_handle_worker, lambda port: (2, port, out), 2, out)
     for r in (0, 1):
         assert out[r]["handles"] == [bytes([1]) * 64, bytes([2]) * 64]
         assert out[r]["ident"] == bytes(range(128))

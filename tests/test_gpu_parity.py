@@ -15,6 +15,8 @@ import pytest
 from cameracalibrations_amd import synthetic as syn
 from cameracalibrations_amd.solver import Solver, fit_model, reference_flags
 
+from _spawn import free_port, spawn_ranks
+
 pytestmark = pytest.mark.gpu
 
 orc = pytest.importorskip("oracle.oracle")
@@ -349,7 +351,7 @@ def test_allreduce_paths_world1(monkeypatch):
         _, base = s.calibrate()
     monkeypatch.delenv("CCAL_WPI")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ["MASTER_PORT"] = str(free_port())
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
@@ -491,12 +493,9 @@ def test_sharded_fit_two_ranks_on_one_gpu():
     wl = syn.named_workload("C2", n_images=n_total)
     with _solver(wl, REF) as s:
         _, base = s.calibrate()
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_two_rank_worker, args=(2, port, n_total, out), nprocs=2, join=True)
+    spawn_ranks(_two_rank_worker, lambda port: (2, port, n_total, out), 2, out)
     assert set(out.keys()) == {0, 1}
     a, b = out[0], out[1]
     assert a["intr"] == b["intr"] and a["rms"] == b["rms"] and a["iters"] == b["iters"]     # replicated state
@@ -527,12 +526,9 @@ def test_sharded_fit_p2p_exchange_on_one_gpu(world, n_total, transport):
     wl = syn.named_workload("C2", n_images=n_total)
     with _solver(wl, REF) as s:
         _, base = s.calibrate()
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_two_rank_worker, args=(world, port, n_total, out, transport), nprocs=world, join=True)
+    spawn_ranks(_two_rank_worker, lambda port: (world, port, n_total, out, transport), world, out)
     assert set(out.keys()) == set(range(world))
     a = out[0]
     for r in range(1, world):
@@ -582,12 +578,9 @@ def test_p2p_silent_peer_times_out_instead_of_hanging():
     import socket
 
     import torch.multiprocessing as mp
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_silent_peer_worker, args=(2, port, out), nprocs=2, join=True)
+    spawn_ranks(_silent_peer_worker, lambda port: (2, port, out), 2, out)
     r = out[0]
     assert r["raised"] and r["status"] == -6, r            # CCAL_E_COMM
     assert r["seconds"] < 5.0 and "timed out" in r["msg"], r
@@ -749,12 +742,9 @@ def test_c3_sharded_over_ranks_matches_oracle(world, transport):
 
     import torch.multiprocessing as mp
     wl, ro = _c3_oracle()
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_c3_shard_worker, args=(world, port, out, transport if transport.startswith("p2p") else "torch", False), nprocs=world, join=True)
+    spawn_ranks(_c3_shard_worker, lambda port: (world, port, out, transport if transport.startswith("p2p") else "torch", False), world, out)
     assert set(out.keys()) == set(range(world))
     a = out[0]
     for r in range(1, world):
@@ -896,12 +886,9 @@ def test_uneven_shards_across_the_exchange_threshold():
     wl = syn.named_workload("C2", n_images=n_total)
     with _solver(wl, REF) as s:
         _, base = s.calibrate()
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_two_rank_worker, args=(2, port, n_total, out, "p2p"), nprocs=2, join=True)
+    spawn_ranks(_two_rank_worker, lambda port: (2, port, n_total, out, "p2p"), 2, out)
     a, b = out[0], out[1]
     assert (a["hi"] - a["lo"], b["hi"] - b["lo"]) == (1281, 1280)
     assert a["intr"] == b["intr"] and a["iters"] == base["iters"] and abs(a["rms"] - base["rms"]) < 1e-12
